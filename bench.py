@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the PyraPose hot path (fwd + losses + bwd + clipnorm-Adam) on N MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+torch.distributed.run with one rank per GPU (RCCL).  Prints ONE JSON line on rank 0.
+
+Workload at N=1 = BASELINE.json configs[1]: LineMOD 13-class training, batch 8, 640x480, ResNet-50 PFPN
++ heads, synthetic data resident in HBM before the timed region (inputs: uint8 U[0,255] minus caffe
+BGR means; targets: the HIP target-assignment kernel on seeded synthetic annotations).  N > 1 is weak
+scaling: batch 8 per GPU, gradient all-reduce over RCCL (pyrapose_amd/parallel.py).
+
+`roofline`: the dominant kernel family is the implicit-GEMM MFMA convolution; every launch of it is
+bracketed with HIP events inside the timed region (torch.cuda.Event on the ctx stream, which IS the
+stream the kernels are launched on) and achieved = sum(algorithmic 2*MAC flops) / sum(durations).
+Peak = 157.3 TFLOP/s dense f32 MFMA (MI355X_MICROARCH.md).  `cpu_baseline` (N=1, rank 0): the oracle's
+PyTorch-CPU float32 restatement of the same train step on a 1-image sample ("port": the Keras/TF
+reference cannot run here or on the GPU box -- tensorflow/keras are not installed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3
+ALGO_GFLOP_PER_IMAGE = {(13, 480, 640): 683.2}  # BASELINE.md §3 (fwd 234.2 + bwd 449.1)
+
+
+def synth_batch(B, H, W, C, seed):
+    """images uint8 U[0,255] - caffe means; K~U{1..3} boxes, sides U[40,160]."""
+    rng = np.random.default_rng(seed)
+    x = rng.integers(0, 256, size=(B, H, W, 3)).astype(np.float32) - np.array([103.939, 116.779, 123.68], np.float32)
+    anns, images = [], []
+    fx, fy, cx, cy = 572.4114, 573.57043, 325.2611, 242.04899
+    for b in range(B):
+        K = int(rng.integers(1, 4))
+        mask = np.zeros((H, W), np.uint8)
+        a = {"mask": [mask], "labels": np.empty((0,)), "bboxes": np.empty((0, 4)), "poses": np.empty((0, 7)),
+             "segmentations": np.empty((0, 8, 3)), "cam_params": np.empty((0, 4)), "mask_ids": np.empty((0,))}
+        for k in range(K):
+            w, h = rng.uniform(40, 160, 2)
+            x1, y1 = rng.uniform(0, W - w), rng.uniform(0, H - h)
+            mask[int(y1):int(y1 + h), int(x1):int(x1 + w)] = k + 1
+            z = 800.0
+            sx, sy, sz = w * z / fx, h * z / fy, rng.uniform(40, 120)
+            box = np.array([[sx / 2, sy / 2, sz / 2], [sx / 2, sy / 2, -sz / 2], [sx / 2, -sy / 2, -sz / 2], [sx / 2, -sy / 2, sz / 2],
+                            [-sx / 2, sy / 2, sz / 2], [-sx / 2, sy / 2, -sz / 2], [-sx / 2, -sy / 2, -sz / 2], [-sx / 2, -sy / 2, sz / 2]], np.float32)
+            tx, ty = ((x1 + w / 2) - cx) * z / fx, ((y1 + h / 2) - cy) * z / fy
+            a["labels"] = np.concatenate([a["labels"], [float(rng.integers(0, C))]])
+            a["bboxes"] = np.concatenate([a["bboxes"], [[x1, y1, x1 + w, y1 + h]]])
+            a["poses"] = np.concatenate([a["poses"], [[tx, ty, z, 1.0, 0.0, 0.0, 0.0]]])
+            a["segmentations"] = np.concatenate([a["segmentations"], [box]])
+            a["cam_params"] = np.concatenate([a["cam_params"], [[fx, fy, cx, cy]]])
+            a["mask_ids"] = np.concatenate([a["mask_ids"], [float(k + 1)]])
+        anns.append(a)
+        images.append(np.zeros((H, W, 3), np.float32))
+    return x, images, anns
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU")
+    ap.add_argument("--classes", type=int, default=13)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+
+    from pyrapose_amd import arch
+    from pyrapose_amd.engine import Engine
+    from pyrapose_amd.parallel import DataParallel
+    from pyrapose_amd.runtime import default_context
+    from pyrapose_amd.utils import anchors as UA
+
+    B, H, W, C = args.batch, args.height, args.width, args.classes
+    ctx = default_context(local_rank)
+    weights = arch.init_weights(C, seed=0)
+    eng = Engine(ctx, C, B, H, W, weights=weights, train=True)
+    if world > 1:
+        DataParallel(eng)
+    x, images, anns = synth_batch(B, H, W, C, seed=1000 + rank)
+    anchors = UA.anchors_for_shape_device((H, W))
+    y_box, y_cls, y_mask = UA.anchor_targets_bbox_device(anchors, images, anns, C)
+    eng.set_targets(y_box, y_cls, y_mask)
+    eng.x_in.copy_(torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.train_step()
+
+    # kernel events on the conv launches (same stream), gathered during the timed steps
+    timed_kinds = ("conv_fwd", "conv_dgrad", "conv_wgrad")
+    records = []
+    if not args.no_kernel_events:
+        def wrap(op):
+            inner = op.fn
+            def fn():
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                inner()
+                e.record()
+                records.append((op.kind, op.name, op.flops, s, e))
+            op.fn = fn
+        for op in eng.fwd_ops + eng.bwd_ops:
+            if op.kind in timed_kinds:
+                wrap(op)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.train_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = eng.losses()
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    images_total = args.steps * B * world
+    value = images_total / dt
+    fwd_fl, bwd_fl = arch.conv_flops(C, H, W)
+    algo_gflop = ALGO_GFLOP_PER_IMAGE.get((C, H, W), (fwd_fl + bwd_fl) / 1e9)
+
+    roofline, kernels = None, []
+    if records:
+        agg = {}
+        for kind, name, flops, s, e in records:
+            a = agg.setdefault(kind, [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += s.elapsed_time(e) * 1e-3
+            a[2] += 1
+        for kind, (fl, sec, n) in agg.items():
+            kernels.append({"kernel": {"conv_fwd": "igemm_kernel<fwd>", "conv_dgrad": "igemm_kernel<bwd-data>",
+                                       "conv_wgrad": "wgrad_kernel"}[kind], "launches": n, "avg_ms": 1e3 * sec / n,
+                            "tflops": fl / sec / 1e12, "share_of_step": sec / dt})
+        dom = max(agg.items(), key=lambda kv: kv[1][1])
+        # the three kernels share one MFMA core; the headline fraction covers the whole conv family
+        fl = sum(v[0] for v in agg.values())
+        sec = sum(v[1] for v in agg.values())
+        roofline = {"bound": "mfma", "achieved": fl / sec / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": fl / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "kernel": "conv implicit-GEMM family (igemm_kernel fwd/bwd-data + wgrad_kernel), f32 MFMA 32x32x2",
+                    "dominant": dom[0], "conv_share_of_step": sec / dt, "per_kernel": kernels}
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import model_torch as MT
+        nb = 1
+        yb, yc, ym = (t[:nb].cpu().numpy() for t in (y_box, y_cls, y_mask))
+        t1 = time.perf_counter()
+        ref_losses, grads, _ = MT.loss_and_grads(weights, x[:nb], yb, yc, ym, C, torch.float32)
+        m = {k: torch.zeros_like(g) for k, g in grads.items()}
+        v = {k: torch.zeros_like(g) for k, g in grads.items()}
+        MT.adam_clipnorm_step(weights, grads, m, v, 1)
+        cpu_dt = time.perf_counter() - t1
+        cpu = {"value": nb / cpu_dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": "1 train step (fwd+loss+bwd+Adam) on %d image of the same synthetic batch, PyTorch-CPU float32 "
+                         "restatement (oracle/model_torch.py), not Keras" % nb}
+
+    out = {
+        "metric": "images/sec 640x480 fwd+bwd (train step: fwd + losses + bwd + clipnorm-Adam)",
+        "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "LineMOD %d-class training, batch %d/GPU, %dx%d, ResNet-50 PFPN + heads (BASELINE configs[1])"
+                               % (C, B, W, H), "global_batch": B * world, "parallelism": "dp%d" % world,
+                   "algorithmic_gflop_per_image": algo_gflop},
+        "step_tflops": images_total * algo_gflop / dt / 1e3,
+        "losses": losses,
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,213 @@
+/* pyrapose_hip.h -- C ABI of the MI355X-native PyraPose hot path (gfx950 / CDNA4).
+ *
+ * Drop-in boundary for the path SURVEY.md §8 scopes: ResNet-50 -> PyraPose feature pyramid ->
+ * shared heads (forward + backward), its losses, optimizer, and the anchor / target / decode ops.
+ * The reference has no operator ABI for this path (it is a Keras graph); each entry
+ * point below names the reference symbol (file:line, relative to the reference repo root) whose
+ * arithmetic it replaces.  The reference's only real C ABI (`uncertainty_pnp/src/ext.h:1-9`) sets
+ * the house style: caller-owned buffers, plain pointers and sizes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *   - tensors are NHWC float32 matrices `[rows][ld]` (row = (image, y, x), ld >= channels);
+ *   - all launches are asynchronous on the ctx stream; no hidden device synchronisation;
+ *   - return: 0 ok; < 0 argument / shape error detected on the host before any launch;
+ *     > 0 a hipError_t.  Never throws, never aborts.  `pp_last_error_string` gives detail.
+ *   - one ctx per (process, device, stream); calls on one ctx are not thread-safe, calls on
+ *     different ctxs are independent.
+ */
+#ifndef PYRAPOSE_HIP_H
+#define PYRAPOSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PP_OK 0
+#define PP_ERR_ARG (-1)
+#define PP_ERR_SHAPE (-2)
+#define PP_ERR_ALIGN (-3)
+#define PP_ERR_NOCTX (-4)
+
+#define PP_MAX_SEG 5
+
+typedef struct pp_ctx pp_ctx;
+
+/* ---- context -------------------------------------------------------------------------- */
+int pp_ctx_create(pp_ctx** out, int device, void* hip_stream);
+void pp_ctx_destroy(pp_ctx* ctx);
+int pp_ctx_set_stream(pp_ctx* ctx, void* hip_stream);
+const char* pp_last_error_string(pp_ctx* ctx);
+const char* pp_version(void);
+/* number of compute units / name of the device the ctx is bound to (for bench metadata) */
+int pp_device_info(pp_ctx* ctx, int* n_cu, char* name_host, int name_len);
+
+/* ---- convolution family ---------------------------------------------------------------
+ * Replaces the TensorFlow conv kernels behind every keras.layers.Conv2D of
+ *   models/retinanet.py:9-54,57-98,101-131 (heads), :180-214 (__create_sparceFPN) and
+ *   keras_resnet.models.ResNet50 called at models/resnet.py:87 (backbone).
+ * Implicit-GEMM direct convolution (no im2col buffer) on v_mfma_f32_32x32x2_f32.
+ *
+ * A "row space" is a list of up to PP_MAX_SEG segments; segment s holds n_img images of
+ * h[s] x w[s] cells, stored image-major, and rows are numbered segment after segment.  One
+ * segment = an ordinary NHWC tensor; several segments = pyramid levels that share weights
+ * (models/retinanet.py:224-225) processed by ONE launch.
+ */
+typedef struct {
+  int n_img;             /* images per segment (batch) */
+  int n_seg;             /* 1..PP_MAX_SEG */
+  int h[PP_MAX_SEG];     /* cells per image, per segment */
+  int w[PP_MAX_SEG];
+} pp_rowspace;
+
+typedef struct {
+  pp_rowspace in;        /* geometry of x (forward input) */
+  pp_rowspace out;       /* geometry of y (forward output); out.n_seg == in.n_seg */
+  int cin, cout;         /* logical channels */
+  int kh, kw, stride;    /* square stride */
+  int pad_t, pad_l;      /* top / left zero padding (TF 'same' with stride 2 on even extents pads
+                            bottom/right only -> pad_t = pad_l = 0; ZeroPadding2D(1) -> 1) */
+  int ld_x, ld_y, ld_w;  /* leading dimensions (floats): x rows, y rows, weight rows.
+                            weights are Keras HWIO flattened: w[(ky*kw+kx)*cin + ci][co], ld_w >= cout,
+                            ld_w % 16 == 0, padding columns zero. cin % 16 == 0, or cin == 4 (packed-RGB stem:
+                            the weight buffer then holds kh*kw*4 rows rounded up to a multiple of 16, zero rows). */
+} pp_conv_desc;
+
+/* y = [relu]( conv(x, w) + bias + residual ).  bias / residual may be NULL.  residual has y's shape
+ * with leading dimension ld_res. */
+int pp_conv2d_nhwc_fwd(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const float* w,
+                       const float* bias, const float* residual, int ld_res, int relu, float* y);
+
+/* dx = mask( conv_transpose(dy, w) + addend ),  mask(v) = relu_src > 0 ? v : 0 (relu_src NULL = no mask).
+ * dy rows have ld_y floats with channels >= cout zero up to the next multiple of 16.
+ * addend / relu_src have dx's shape (leading dims ld_add / ld_rs). */
+int pp_conv2d_nhwc_bwd_data(pp_ctx* ctx, const pp_conv_desc* d, const float* dy, const float* w,
+                            const float* addend, int ld_add, const float* relu_src, int ld_rs, float* dx);
+
+/* dw += x^T (*) dy  (atomic accumulation into a caller-zeroed HWIO buffer, ld_w);  if dbias != NULL,
+ * dbias[co] += sum_rows dy[row][co]. */
+int pp_conv2d_nhwc_bwd_weight(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const float* dy,
+                              float* dw, float* dbias);
+
+/* ---- pooling / resampling / pointwise --------------------------------------------------
+ * keras_resnet pool1 = MaxPooling2D(3, strides 2, 'same') (called via models/resnet.py:87). */
+int pp_maxpool3x3s2_fwd(pp_ctx* ctx, int n_img, int h, int w, int c, const float* x, int oh, int ow, float* y);
+/* UpsampleLike: layers/_misc.py:96-109 -> backend/tf_backend.py:28-35 (tf.image.resize NEAREST, TF 2.1:
+ * src = floor((dst + 0.5) * in / out)).   out = up(src) + other  (other may be NULL). */
+int pp_upsample_nearest_add_fwd(pp_ctx* ctx, int n_img, int sh, int sw, int th, int tw, int c,
+                                const float* src, const float* other, float* out);
+/* dsrc = base + sum over the target cells that map to each source cell of dtarget (base may be NULL) */
+int pp_upsample_nearest_add_bwd(pp_ctx* ctx, int n_img, int sh, int sw, int th, int tw, int c,
+                                const float* dtarget, const float* base, float* dsrc);
+/* out = a + b (+ c)   (keras.layers.Add, models/retinanet.py:198-211); b, c may be NULL */
+int pp_add_n(pp_ctx* ctx, size_t n, const float* a, const float* b, const float* c, float* out);
+/* [n_img,h,w,3] -> [n_img,h,w,4] zero-padded channel (feeds conv1 as cin == 4) */
+int pp_pack_rgb_to_4(pp_ctx* ctx, size_t n_pixels, const float* x3, float* x4);
+
+/* ---- head output export ---------------------------------------------------------------
+ * Head convs write level-major matrices [rows][ld]; Keras concatenates the per-level reshapes on
+ * axis 1 (models/retinanet.py:224-229) and applies sigmoid to cls / mask (:52, :96).
+ * out[b][level_off + cell*A + a][v] = f(src[row(level,b,cell)][a*V + v]),  f = sigmoid or identity. */
+int pp_export_head(pp_ctx* ctx, const pp_rowspace* rs, int n_anchor, int n_val, const float* src, int ld,
+                   int apply_sigmoid, float* out);
+
+/* ---- losses -----------------------------------------------------------------------------
+ * counts[0..2] += #(state == 1) in y_true_3dbox / y_true_cls / y_true_mask (last column).
+ * Normalisers of losses.py:62-66 and :402-405 (over the WHOLE batch). */
+int pp_count_positives(pp_ctx* ctx, size_t rows_box, const float* y_box, size_t rows_cls, int c_cls,
+                       const float* y_cls, size_t rows_mask, int c_mask, const float* y_mask, int* counts);
+/* focal(alpha, gamma): losses.py:22-68 (cls and mask heads, bin/train.py:98-99).
+ * logits: level-major [rows][ld] pre-sigmoid; y_true: Keras layout (B, N, C+1);
+ * loss_sum += sum(focal)/normaliser; dlogits (same layout as logits, padding channels zeroed)
+ * = d(loss)/d(logit) * loss_weight.  normaliser = max(1, *count).  dlogits may be NULL. */
+int pp_sigmoid_focal_fwd_bwd(pp_ctx* ctx, const pp_rowspace* rs, int n_anchor, int n_class,
+                             const float* logits, int ld, const float* y_true, float alpha, float gamma,
+                             const int* count, float loss_weight, float* loss_sum, float* dlogits);
+/* orthogonal_l1(weight .125, sigma 3): losses.py:321-408 ('3Dbox', bin/train.py:97). */
+int pp_orth_smoothl1_fwd_bwd(pp_ctx* ctx, const pp_rowspace* rs, int n_anchor, const float* pred, int ld,
+                             const float* y_true, float weight, float sigma, const int* count,
+                             float loss_weight, float* loss_sum, float* dpred);
+
+/* ---- optimizer: keras 2.3.1 Adam(lr, clipnorm) as compiled at bin/train.py:101 --------
+ * A parameter set is a flat float32 buffer cut into tensors described by pp_param_desc. */
+typedef struct {
+  long long offset;      /* first element in the flat buffers */
+  long long count;       /* elements (rows * ld) */
+  int ld;                /* row length; scale index = element % ld */
+  int trainable;         /* 0 = frozen (models/resnet.py:100-103) */
+  long long scale_off;   /* offset into `scales` of the per-output-channel frozen-BN scale, or -1 */
+  float l2;              /* kernel_regularizer l2 coefficient (models/retinanet.py:108), else 0 */
+} pp_param_desc;
+
+typedef struct pp_optimizer pp_optimizer;
+int pp_optimizer_create(pp_ctx* ctx, pp_optimizer** out, const pp_param_desc* descs_host, int n_desc,
+                        long long total);
+void pp_optimizer_destroy(pp_optimizer* opt);
+/* gnorm_sq[0] = sum over trainable tensors of || scale * g_eff + 2*l2*w ||^2 (fixed reduction order).
+ * l2_loss (may be NULL) += sum l2 * w^2. */
+int pp_grad_global_norm(pp_ctx* ctx, pp_optimizer* opt, const float* w_master, const float* g_eff,
+                        const float* scales, float* gnorm_sq, float* l2_loss);
+/* One Adam step with global-norm clipping (scale every gradient by clipnorm/norm when norm >= clipnorm);
+ * rewrites w_eff = w_master * scale.  `step` is 1-based: lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t). */
+int pp_adam_step_clipnorm(pp_ctx* ctx, pp_optimizer* opt, float* w_master, float* w_eff, const float* g_eff,
+                          const float* scales, float* m, float* v, const float* gnorm_sq, float lr,
+                          float beta1, float beta2, float eps, float clipnorm, long long step);
+
+/* ---- anchors / targets / decode -----------------------------------------------------------
+ * utils/anchors.py:447-478 (generate_anchors) -- host, float64, bit-exact op order. */
+int pp_generate_base_anchors_host(int base_size, const float* ratios_host, int n_ratios,
+                                  const float* scales_host, int n_scales, double* out_host);
+/* utils/anchors.py:415-444 + :372-412: all levels, float64 [N,4].  base_anchors_host: [n_levels][A][4]. */
+int pp_anchors_shift_f64(pp_ctx* ctx, int n_levels, const int* feat_h_host, const int* feat_w_host,
+                         const int* strides_host, int n_anchor, const double* base_anchors_host,
+                         double* anchors_out);
+/* layers/_misc.py:60-71 -> backend/common.py:93-116: float32 device-side anchors [N,4]. */
+int pp_anchors_shift_f32(pp_ctx* ctx, int n_levels, const int* feat_h_host, const int* feat_w_host,
+                         const int* strides_host, int n_anchor, const double* base_anchors_host,
+                         float* anchors_out);
+/* utils/compute_overlap.pyx:13-53: float64 IoU, '+1' convention, [N,K] row-major. */
+int pp_compute_overlap_f64(pp_ctx* ctx, int n, const double* boxes, int k, const double* query, double* overlaps);
+/* utils/anchors.py:290-318: first-max argmax + thresholds. state: 1 positive, -1 ignore, 0 background. */
+int pp_compute_gt_annotations(pp_ctx* ctx, int n, const double* anchors, int k, const double* gt_boxes,
+                              double negative_overlap, double positive_overlap, int* argmax, signed char* state);
+
+/* utils/anchors.py:72-287 anchor_targets_bbox, whole batch in one call.
+ * Ground truth is packed: image b owns gt_offset_host[b] .. gt_offset_host[b+1]-1.
+ *   gt_boxes  [G,4] f64 (x1,y1,x2,y2);  gt_labels [G] i32;  gt_box3d [G,16] f64 projected corner
+ *   pixels (anchors.py:207-215 is evaluated by pp_project_box3d_host);  gt_mask_ids [G] i32;
+ *   id_masks: uint8 [B, mask_h, mask_w] object-id images, image b valid in its top-left
+ *   mask_hw_host[b] = (h, w) corner (NULL = all full size);  image_hw_host [B,2] unpadded image sizes.
+ * Outputs (float32, Keras layout, fully written): regression [B,N,17], labels [B,N,C+1],
+ * mask [B,MH*MW,C+1] with (MH,MW) = level-3 shape of image 0. */
+int pp_anchor_targets(pp_ctx* ctx, int n_anchor_total, const double* anchors, int batch,
+                      const int* gt_offset_host, const double* gt_boxes, const int* gt_labels,
+                      const double* gt_box3d, const int* gt_mask_ids, const unsigned char* id_masks,
+                      int mask_h, int mask_w, const int* mask_hw_host, const int* image_hw_host, int num_classes,
+                      double negative_overlap, double positive_overlap, int out_mh, int out_mw,
+                      float* regression, float* labels, float* mask);
+/* utils/anchors.py:207-215 + toPix_array :562-567 (host, float64; quat2mat = transforms3d 0.3.1). */
+int pp_project_box3d_host(const double* pose7_host, const double* box8x3_host, const double* cam4_host,
+                          double* out16_host);
+/* PIL NEAREST index map used at anchors.py:158 (host). */
+int pp_pil_nearest_index_host(int n_in, int n_out, int* out_host);
+
+/* layers/_misc.py:195-197 -> backend/common.py:25-56: boxes3D = anchors (+) 0.2 * reg * (w|h), float32. */
+int pp_box3d_decode(pp_ctx* ctx, int batch, int n, const float* anchors, const float* regression, float* boxes3d);
+/* utils/linemod_eval.py:317-319: per (image, class) ascending indices with score > thr.
+ * idx_out [B,C,cap] (int32, -1 padded), counts [B,C]. */
+int pp_score_threshold_compact(pp_ctx* ctx, int batch, int n, int n_class, const float* scores, float thr,
+                               int cap, int* idx_out, int* counts);
+/* layers/filter_detections.py:21-118 (class-specific, NMS on).  boxes [N,4], boxes3d [N,16],
+ * scores [N,C] for ONE image.  Outputs padded with -1 to max_det.  workspace >= pp_filter_workspace_bytes. */
+size_t pp_filter_workspace_bytes(int n, int n_class, int max_det);
+int pp_filter_detections(pp_ctx* ctx, int n, int n_class, const float* boxes, const float* boxes3d,
+                         const float* scores, float score_thr, float iou_thr, int max_det, void* workspace,
+                         float* out_boxes, float* out_boxes3d, float* out_scores, int* out_labels);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYRAPOSE_HIP_H */

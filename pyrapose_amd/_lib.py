@@ -1,0 +1,124 @@
+"""ctypes binding of libpyrapose_hip.so (the C ABI declared in include/pyrapose_hip.h).
+
+There is NO fallback: if the shared library is missing or fails to load, importing this module
+raises ImportError, and every op raises on a non-zero status.  Negative statuses (argument / shape
+errors caught on the host) become ValueError -- mirroring the ValueError the reference's Cython
+boundary raises on a wrong dtype/ndim (utils/compute_overlap.pyx:13-16) -- positive ones
+(hipError_t) become RuntimeError.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpyrapose_hip.so")
+
+PP_MAX_SEG = 5
+
+
+class RowSpace(C.Structure):
+    _fields_ = [("n_img", C.c_int), ("n_seg", C.c_int), ("h", C.c_int * PP_MAX_SEG), ("w", C.c_int * PP_MAX_SEG)]
+
+    @classmethod
+    def make(cls, n_img, shapes):
+        rs = cls()
+        rs.n_img = int(n_img)
+        rs.n_seg = len(shapes)
+        for i, (h, w) in enumerate(shapes):
+            rs.h[i] = int(h)
+            rs.w[i] = int(w)
+        return rs
+
+    def rows(self):
+        return sum(self.n_img * self.h[i] * self.w[i] for i in range(self.n_seg))
+
+    def shapes(self):
+        return [(self.h[i], self.w[i]) for i in range(self.n_seg)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("in_", RowSpace), ("out", RowSpace), ("cin", C.c_int), ("cout", C.c_int), ("kh", C.c_int),
+                ("kw", C.c_int), ("stride", C.c_int), ("pad_t", C.c_int), ("pad_l", C.c_int), ("ld_x", C.c_int),
+                ("ld_y", C.c_int), ("ld_w", C.c_int)]
+
+
+class ParamDesc(C.Structure):
+    _fields_ = [("offset", C.c_longlong), ("count", C.c_longlong), ("ld", C.c_int), ("trainable", C.c_int),
+                ("scale_off", C.c_longlong), ("l2", C.c_float)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "pyrapose_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C pyrapose_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    try:
+        return C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise ImportError("pyrapose_amd: cannot load %s: %s" % (LIB_PATH, e))
+
+
+lib = _load()
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_d = C.c_double
+_ll = C.c_longlong
+_sz = C.c_size_t
+
+_SIGS = {
+    "pp_ctx_create": (_i, [C.POINTER(_p), _i, _p]),
+    "pp_ctx_destroy": (None, [_p]),
+    "pp_ctx_set_stream": (_i, [_p, _p]),
+    "pp_last_error_string": (C.c_char_p, [_p]),
+    "pp_version": (C.c_char_p, []),
+    "pp_device_info": (_i, [_p, C.POINTER(_i), C.c_char_p, _i]),
+    "pp_conv2d_nhwc_fwd": (_i, [_p, C.POINTER(ConvDesc), _p, _p, _p, _p, _i, _i, _p]),
+    "pp_conv2d_nhwc_bwd_data": (_i, [_p, C.POINTER(ConvDesc), _p, _p, _p, _i, _p, _i, _p]),
+    "pp_conv2d_nhwc_bwd_weight": (_i, [_p, C.POINTER(ConvDesc), _p, _p, _p, _p]),
+    "pp_maxpool3x3s2_fwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p]),
+    "pp_upsample_nearest_add_fwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "pp_upsample_nearest_add_bwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "pp_add_n": (_i, [_p, _sz, _p, _p, _p, _p]),
+    "pp_pack_rgb_to_4": (_i, [_p, _sz, _p, _p]),
+    "pp_export_head": (_i, [_p, C.POINTER(RowSpace), _i, _i, _p, _i, _i, _p]),
+    "pp_count_positives": (_i, [_p, _sz, _p, _sz, _i, _p, _sz, _i, _p, _p]),
+    "pp_sigmoid_focal_fwd_bwd": (_i, [_p, C.POINTER(RowSpace), _i, _i, _p, _i, _p, _f, _f, _p, _f, _p, _p]),
+    "pp_orth_smoothl1_fwd_bwd": (_i, [_p, C.POINTER(RowSpace), _i, _p, _i, _p, _f, _f, _p, _f, _p, _p]),
+    "pp_optimizer_create": (_i, [_p, C.POINTER(_p), C.POINTER(ParamDesc), _i, _ll]),
+    "pp_optimizer_destroy": (None, [_p]),
+    "pp_grad_global_norm": (_i, [_p, _p, _p, _p, _p, _p, _p]),
+    "pp_adam_step_clipnorm": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _f, _f, _ll]),
+    "pp_generate_base_anchors_host": (_i, [_i, C.POINTER(_f), _i, C.POINTER(_f), _i, C.POINTER(_d)]),
+    "pp_anchors_shift_f64": (_i, [_p, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i, C.POINTER(_d), _p]),
+    "pp_anchors_shift_f32": (_i, [_p, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i, C.POINTER(_d), _p]),
+    "pp_compute_overlap_f64": (_i, [_p, _i, _p, _i, _p, _p]),
+    "pp_compute_gt_annotations": (_i, [_p, _i, _p, _i, _p, _d, _d, _p, _p]),
+    "pp_anchor_targets": (_i, [_p, _i, _p, _i, C.POINTER(_i), _p, _p, _p, _p, _p, _i, _i, C.POINTER(_i), C.POINTER(_i), _i, _d, _d,
+                               _i, _i, _p, _p, _p]),
+    "pp_project_box3d_host": (_i, [C.POINTER(_d), C.POINTER(_d), C.POINTER(_d), C.POINTER(_d)]),
+    "pp_pil_nearest_index_host": (_i, [_i, _i, C.POINTER(_i)]),
+    "pp_box3d_decode": (_i, [_p, _i, _i, _p, _p, _p]),
+    "pp_score_threshold_compact": (_i, [_p, _i, _i, _i, _p, _f, _i, _p, _p]),
+    "pp_filter_workspace_bytes": (_sz, [_i, _i, _i]),
+    "pp_filter_detections": (_i, [_p, _i, _i, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p]),
+}
+
+EXPORTS = sorted(_SIGS)
+
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)  # AttributeError here = the .so does not export what the header declares
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def check(rc, ctx=None, what=""):
+    if rc == 0:
+        return
+    msg = ""
+    if ctx is not None:
+        s = lib.pp_last_error_string(ctx)
+        msg = s.decode("utf-8", "replace") if s else ""
+    if rc < 0:
+        raise ValueError("%s failed (%d): %s" % (what or "pyrapose_hip", rc, msg))
+    raise RuntimeError("%s failed (hipError %d): %s" % (what or "pyrapose_hip", rc, msg))

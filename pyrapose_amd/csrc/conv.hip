@@ -1,0 +1,612 @@
+// Implicit-GEMM direct convolution (NHWC, float32) on v_mfma_f32_32x32x2_f32 for gfx950.
+//
+//   forward   y[m][co]  = sum_{tap,ci} x[gather(m,tap)][ci] * w[tap][ci][co]        (+bias, +residual, relu)
+//   bwd-data  dx[m][ci] = sum_{tap,co} dy[gather'(m,tap)][co] * w[tap][ci][co]      (+addend, relu mask)
+//   bwd-wgt   dw[tap][ci][co] += sum_m x[gather(m,tap)][ci] * dy[m][co]             (split over m, f32 atomics)
+//
+// Replaces the TF conv kernels behind every Conv2D of the reference graph
+// (models/retinanet.py:9-131,180-214; keras_resnet ResNet50 via models/resnet.py:87).
+//
+// Design:  no im2col buffer -- the A tile is gathered straight from the NHWC
+// activation into LDS, 16 reduction channels per step, stored k-major ([16][BM], rows rotated by
+// 8*(k/4) so the transposing ds_write_b32 are conflict-free) so that each lane fetches the TM (TN)
+// operands of its interleaved 32x32 sub-tiles with ONE ds_read_b{32,64,128}.  One wave owns a
+// (32*TM)x(32*TN) output tile = TM*TN accumulators of v_mfma_f32_32x32x2_f32 (exact f32 fma chain,
+// 64 cycles/SIMD each), 4 waves (2x2) per workgroup, LDS double-buffered with register staging
+// (global loads for step s+1 are in flight under the MFMAs of step s; one barrier per step).
+// Pyramid levels that share weights are ONE launch: rows are numbered level after level ("row
+// space", pyrapose_hip.h) and only the gather knows the per-level geometry.
+#include "pp_internal.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct SegGeo {
+  int row_begin;      // first row (m) of the segment in the space the kernel enumerates
+  int src_row_begin;  // first row of the segment in the gathered tensor
+  int OH, OW;         // cells per image in the enumerated space
+  int SH, SW;         // cells per image in the gathered tensor
+};
+
+struct IgemmParams {
+  const float* src;
+  const float* wgt;
+  float* out;
+  const float* bias;
+  const float* addend;
+  const float* mask_src;
+  int ld_src, ld_w, ld_out, ld_add, ld_mask;
+  int relu;
+  int M, n_seg;
+  SegGeo seg[PP_MAX_SEG];
+  int Cred;        // reduction channels per tap (multiple of 16, or 4 for the packed-RGB stem)
+  int Nout;        // output channels
+  int w_tap_rows;  // weight rows per tap (= cin of the forward conv)
+  int kh, kw;
+  int mul, tsign, off_y, off_x, div;  // src = (pos*mul + tap*tsign + off) / div
+  int n_tiles_n;
+};
+
+template <int V>
+struct VecT;
+template <>
+struct VecT<1> { typedef float type; };
+template <>
+struct VecT<2> { typedef float2 type; };
+template <>
+struct VecT<4> { typedef float4 type; };
+
+__device__ __forceinline__ float vec_get(float v, int) { return v; }
+__device__ __forceinline__ float vec_get(float2 v, int i) { return i == 0 ? v.x : v.y; }
+__device__ __forceinline__ float vec_get(float4 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+
+struct RowPos {
+  int ybase, xbase, rowbase, SH, SW;
+  bool ok;
+};
+
+// m -> (segment, image, y, x) -> gather bases.  n_seg <= PP_MAX_SEG, uniform loop + selects.
+__device__ __forceinline__ RowPos decode_row(const IgemmParams& p, int m) {
+  RowPos r;
+  r.ok = m < p.M;
+  int rb = p.seg[0].row_begin, sb = p.seg[0].src_row_begin, OH = p.seg[0].OH, OW = p.seg[0].OW,
+      SH = p.seg[0].SH, SW = p.seg[0].SW;
+  for (int s = 1; s < p.n_seg; ++s) {
+    if (m >= p.seg[s].row_begin) {
+      rb = p.seg[s].row_begin; sb = p.seg[s].src_row_begin; OH = p.seg[s].OH; OW = p.seg[s].OW;
+      SH = p.seg[s].SH; SW = p.seg[s].SW;
+    }
+  }
+  int local = r.ok ? m - rb : 0;
+  int hw = OH * OW;
+  int n = local / hw;
+  int rem = local - n * hw;
+  int y = rem / OW;
+  int x = rem - y * OW;
+  r.ybase = y * p.mul + p.off_y;
+  r.xbase = x * p.mul + p.off_x;
+  r.rowbase = sb + n * SH * SW;
+  r.SH = SH;
+  r.SW = SW;
+  return r;
+}
+
+__device__ __forceinline__ bool tap_offset(const IgemmParams& p, const RowPos& r, int ty, int tx, long long* off) {
+  int sy = r.ybase + ty * p.tsign;
+  int sx = r.xbase + tx * p.tsign;
+  bool ok = r.ok;
+  if (p.div > 1) {
+    ok = ok && (sy % p.div == 0) && (sx % p.div == 0);
+    sy /= p.div;
+    sx /= p.div;
+  }
+  ok = ok && ((unsigned)sy < (unsigned)r.SH) && ((unsigned)sx < (unsigned)r.SW);
+  *off = ok ? (long long)(r.rowbase + sy * r.SW + sx) * p.ld_src : 0;
+  return ok;
+}
+
+// TM, TN in {1,2,4}: per-wave tile (32*TM)x(32*TN); workgroup tile BM=64*TM, BN=64*TN (2x2 waves).
+// BT: the B (weight) tile is read transposed -- rows = output channel, 16 contiguous reduction
+// channels (bwd-data);  SMALLC: packed-RGB stem, Cred == 4, one tap per float4.
+template <int TM, int TN, bool BT, bool SMALLC>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
+  constexpr int BM = 64 * TM, BN = 64 * TN, BK = 16;
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
+  float* As = smem;
+  float* Bs = smem + 2 * BK * BM;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile_n = blockIdx.x % p.n_tiles_n, tile_m = blockIdx.x / p.n_tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- A loader: thread -> rows r0 + 64*i, 4 consecutive reduction channels 4*kq ----
+  const int kq = tid & 3, r0 = tid >> 2;
+  RowPos rows[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) rows[i] = decode_row(p, m0 + r0 + 64 * i);
+  long long a_off[TM];
+  bool a_ok[TM];
+
+  const int n_taps = p.kh * p.kw;
+  const int steps_per_tap = SMALLC ? 1 : p.Cred / BK;
+  const int n_steps = SMALLC ? (n_taps * 4 + BK - 1) / BK : n_taps * steps_per_tap;
+
+  // ---- B loader ----
+  // !BT: rows = k (16), float4 along output channels.  BT: rows = output channel, float4 along k.
+  const int b_nq = tid % (BN / 4), b_kb = tid / (BN / 4);
+
+  float4 ra[TM], rb[TN];
+  int tap = 0, ty = 0, tx = 0, red0 = 0;  // current tap and reduction-channel offset of the step being loaded
+
+  auto set_tap = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_ok[i] = tap_offset(p, rows[i], ty, tx, &a_off[i]);
+  };
+
+  auto load_step = [&](int step) {
+    if (SMALLC) {
+      // one tap per float4: this thread's tap = step*4 + kq
+      int t = step * 4 + kq;
+      int tyy = t / p.kw, txx = t - tyy * p.kw;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        long long off;
+        bool ok = (t < n_taps) && tap_offset(p, rows[i], tyy, txx, &off);
+        ra[i] = ok ? *reinterpret_cast<const float4*>(p.src + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ra[i] = a_ok[i] ? *reinterpret_cast<const float4*>(p.src + a_off[i] + red0 + 4 * kq)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    if (!BT) {
+      const int wrow0 = SMALLC ? step * BK : tap * p.w_tap_rows + red0;
+      const int c = n0 + 4 * b_nq;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        int k = b_kb + (1024 / BN) * i;
+        rb[i] = (c < p.ld_w) ? *reinterpret_cast<const float4*>(p.wgt + (long long)(wrow0 + k) * p.ld_w + c)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        int n = n0 + r0 + 64 * i;
+        rb[i] = (n < p.Nout)
+                    ? *reinterpret_cast<const float4*>(p.wgt + (long long)(tap * p.w_tap_rows + n) * p.ld_w + red0 + 4 * kq)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+
+  auto advance = [&]() {
+    if (!SMALLC) {
+      red0 += BK;
+      if (red0 >= p.Cred) {
+        red0 = 0;
+        ++tap;
+        ++tx;
+        if (tx == p.kw) { tx = 0; ++ty; }
+        set_tap();
+      }
+    }
+  };
+
+  auto store_step = [&](int buf) {
+    float* A = As + buf * BK * BM;
+    float* B = Bs + buf * BK * BN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      int col = (r0 + 64 * i + 8 * kq) & (BM - 1);
+      A[(4 * kq + 0) * BM + col] = ra[i].x;
+      A[(4 * kq + 1) * BM + col] = ra[i].y;
+      A[(4 * kq + 2) * BM + col] = ra[i].z;
+      A[(4 * kq + 3) * BM + col] = ra[i].w;
+    }
+    if (!BT) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        int k = b_kb + (1024 / BN) * i;
+        *reinterpret_cast<float4*>(B + k * BN + 4 * b_nq) = rb[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        int col = (r0 + 64 * i + 8 * kq) & (BN - 1);
+        B[(4 * kq + 0) * BN + col] = rb[i].x;
+        B[(4 * kq + 1) * BN + col] = rb[i].y;
+        B[(4 * kq + 2) * BN + col] = rb[i].z;
+        B[(4 * kq + 3) * BN + col] = rb[i].w;
+      }
+    }
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int il = lane & 31, h = lane >> 5;
+  const int a_col = wm * 32 * TM + il * TM;
+  const int b_col = wn * 32 * TN + il * TN;
+  typedef typename VecT<TM>::type AV;
+  typedef typename VecT<TN>::type BV;
+
+  if (!SMALLC) set_tap();
+  load_step(0);
+  store_step(0);
+  __syncthreads();
+
+  for (int step = 0; step < n_steps; ++step) {
+    const int buf = step & 1;
+    const bool more = step + 1 < n_steps;
+    if (more) {
+      advance();
+      load_step(step + 1);
+    }
+    const float* A = As + buf * BK * BM;
+    const float* B = Bs + buf * BK * BN;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const int k = kk + h;
+      const int rot = 8 * (kk >> 2);
+      AV av = *reinterpret_cast<const AV*>(A + k * BM + ((a_col + rot) & (BM - 1)));
+      BV bv = *reinterpret_cast<const BV*>(B + k * BN + ((b_col + (BT ? rot : 0)) & (BN - 1)));
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vec_get(av, a), vec_get(bv, b), acc[a][b], 0, 0, 0);
+    }
+    if (more) store_step(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: +bias, +addend, relu-mask, relu ----
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row_local = wm * 32 * TM + ((r & 3) + 8 * (r >> 2) + 4 * h) * TM + a;
+      const int m = m0 + row_local;
+      if (m >= p.M) continue;
+      const int co0 = n0 + b_col;
+      float v[TN];
+#pragma unroll
+      for (int b = 0; b < TN; ++b) v[b] = acc[a][b][r];
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int co = co0 + b;
+        if (co < p.Nout) {
+          if (p.bias) v[b] += p.bias[co];
+          if (p.addend) v[b] += p.addend[(long long)m * p.ld_add + co];
+          if (p.mask_src) v[b] = p.mask_src[(long long)m * p.ld_mask + co] > 0.f ? v[b] : 0.f;
+          if (p.relu) v[b] = fmaxf(v[b], 0.f);
+        }
+      }
+      float* dst = p.out + (long long)m * p.ld_out + co0;
+      if (co0 + TN <= p.Nout && (p.ld_out % TN) == 0) {
+        if (TN == 1) dst[0] = v[0];
+        if (TN == 2) *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[TN > 1 ? 1 : 0]);
+        if (TN == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[TN > 1 ? 1 : 0], v[TN > 2 ? 2 : 0], v[TN > 3 ? 3 : 0]);
+      } else {
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          if (co0 + b < p.Nout) dst[b] = v[b];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient
+struct WgradParams {
+  const float* src;
+  const float* dy;
+  float* dw;
+  float* dbias;
+  int ld_src, ld_dy, ld_w;
+  int M, n_seg;
+  SegGeo seg[PP_MAX_SEG];
+  int Cin, Cout;
+  int kh, kw, stride, pad_t, pad_l;
+  int k_tiles_per_tap, n_tiles_k, n_tiles_n, splits, rows_per_split;
+};
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
+  constexpr int BM = 64 * TM, BN = 64 * TN, BK = 16;
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
+  float* As = smem;
+  float* Bs = smem + 2 * BK * BM;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int b = blockIdx.x;
+  const int tile_n = b % p.n_tiles_n;
+  b /= p.n_tiles_n;
+  const int tile_k = b % p.n_tiles_k;
+  const int split = b / p.n_tiles_k;
+  const int tap = tile_k / p.k_tiles_per_tap;
+  const int ci0 = (tile_k - tap * p.k_tiles_per_tap) * BM;
+  const int ty = tap / p.kw, tx = tap - ty * p.kw;
+  const int n0 = tile_n * BN;
+  const int m_begin = split * p.rows_per_split;
+  const int m_end = min(p.M, m_begin + p.rows_per_split);
+  const int n_steps = (m_end - m_begin + BK - 1) / BK;
+
+  const int a_cq = tid % (BM / 4), a_rb = tid / (BM / 4);  // rows a_rb + (1024/BM)*i
+  const int b_cq = tid % (BN / 4), b_rb = tid / (BN / 4);
+
+  float4 ra[TM], rb[TN];
+
+  auto load_step = [&](int step) {
+    const int mb = m_begin + step * BK;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = mb + a_rb + (1024 / BM) * i;
+      bool ok = m < m_end;
+      int rbeg = p.seg[0].row_begin, sb = p.seg[0].src_row_begin, OH = p.seg[0].OH, OW = p.seg[0].OW,
+          SH = p.seg[0].SH, SW = p.seg[0].SW;
+      for (int s = 1; s < p.n_seg; ++s) {
+        if (m >= p.seg[s].row_begin) {
+          rbeg = p.seg[s].row_begin; sb = p.seg[s].src_row_begin; OH = p.seg[s].OH; OW = p.seg[s].OW;
+          SH = p.seg[s].SH; SW = p.seg[s].SW;
+        }
+      }
+      int local = ok ? m - rbeg : 0;
+      int hw = OH * OW;
+      int n = local / hw;
+      int rem = local - n * hw;
+      int y = rem / OW;
+      int x = rem - y * OW;
+      int sy = y * p.stride + ty - p.pad_t;
+      int sx = x * p.stride + tx - p.pad_l;
+      ok = ok && ((unsigned)sy < (unsigned)SH) && ((unsigned)sx < (unsigned)SW);
+      ra[i] = ok ? *reinterpret_cast<const float4*>(p.src + (long long)(sb + n * SH * SW + sy * SW + sx) * p.ld_src + ci0 + 4 * a_cq)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int m = mb + b_rb + (1024 / BN) * i;
+      const int c = n0 + 4 * b_cq;
+      rb[i] = (m < m_end && c < p.ld_dy) ? *reinterpret_cast<const float4*>(p.dy + (long long)m * p.ld_dy + c)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_step = [&](int buf) {
+    float* A = As + buf * BK * BM;
+    float* B = Bs + buf * BK * BN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) *reinterpret_cast<float4*>(A + (a_rb + (1024 / BM) * i) * BM + 4 * a_cq) = ra[i];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) *reinterpret_cast<float4*>(B + (b_rb + (1024 / BN) * i) * BN + 4 * b_cq) = rb[i];
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int c = 0; c < TN; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+  float bias_sum = 0.f;
+  const bool do_bias = (p.dbias != nullptr) && (tile_k == 0) && (tid < BN);
+
+  const int il = lane & 31, h = lane >> 5;
+  const int a_col = wm * 32 * TM + il * TM;
+  const int b_col = wn * 32 * TN + il;  // blocked columns: + 32*c
+  typedef typename VecT<TM>::type AV;
+
+  if (n_steps > 0) {
+    load_step(0);
+    store_step(0);
+  }
+  __syncthreads();
+  for (int step = 0; step < n_steps; ++step) {
+    const int buf = step & 1;
+    const bool more = step + 1 < n_steps;
+    if (more) load_step(step + 1);
+    const float* A = As + buf * BK * BM;
+    const float* B = Bs + buf * BK * BN;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const int k = kk + h;
+      AV av = *reinterpret_cast<const AV*>(A + k * BM + a_col);
+      float bv[TN];
+#pragma unroll
+      for (int c = 0; c < TN; ++c) bv[c] = B[k * BN + b_col + 32 * c];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int c = 0; c < TN; ++c)
+          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(vec_get(av, a), bv[c], acc[a][c], 0, 0, 0);
+    }
+    if (do_bias) {
+#pragma unroll
+      for (int k = 0; k < BK; ++k) bias_sum += B[k * BN + tid];
+    }
+    if (more) store_step(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row_local = wm * 32 * TM + ((r & 3) + 8 * (r >> 2) + 4 * h) * TM + a;
+      const int ci = ci0 + row_local;
+      float* dst = p.dw + (long long)(tap * p.Cin + ci) * p.ld_w;
+#pragma unroll
+      for (int c = 0; c < TN; ++c) {
+        const int co = n0 + b_col + 32 * c;
+        if (co < p.Cout) atomicAdd(dst + co, acc[a][c][r]);
+      }
+    }
+  }
+  if (do_bias && n0 + tid < p.Cout) atomicAdd(p.dbias + n0 + tid, bias_sum);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+static int fill_segs(pp_ctx* ctx, const pp_conv_desc* d, bool enumerate_out, SegGeo* seg, int* M_out) {
+  // enumerate_out: rows enumerate the OUTPUT space and gather from the input (fwd, wgrad);
+  // otherwise rows enumerate the INPUT space and gather from the output-space tensor (bwd-data).
+  const pp_rowspace* e = enumerate_out ? &d->out : &d->in;
+  const pp_rowspace* g = enumerate_out ? &d->in : &d->out;
+  long long rb = 0, sb = 0;
+  for (int s = 0; s < e->n_seg; ++s) {
+    seg[s].row_begin = (int)rb;
+    seg[s].src_row_begin = (int)sb;
+    seg[s].OH = e->h[s]; seg[s].OW = e->w[s];
+    seg[s].SH = g->h[s]; seg[s].SW = g->w[s];
+    rb += (long long)e->n_img * e->h[s] * e->w[s];
+    sb += (long long)g->n_img * g->h[s] * g->w[s];
+  }
+  *M_out = (int)rb;
+  (void)ctx;
+  return 0;
+}
+
+static int check_desc(pp_ctx* ctx, const pp_conv_desc* d, const char* who) {
+  PP_CHECK_ARG(ctx, d != nullptr, PP_ERR_ARG, "%s: null descriptor", who);
+  PP_CHECK_ARG(ctx, pp_rowspace_ok(&d->in) && pp_rowspace_ok(&d->out), PP_ERR_SHAPE, "%s: bad row space", who);
+  PP_CHECK_ARG(ctx, d->in.n_seg == d->out.n_seg && d->in.n_img == d->out.n_img, PP_ERR_SHAPE,
+               "%s: in/out row spaces disagree", who);
+  PP_CHECK_ARG(ctx, d->kh > 0 && d->kw > 0 && d->kh <= 7 && d->kw <= 7 && d->stride >= 1 && d->stride <= 2, PP_ERR_SHAPE,
+               "%s: unsupported kernel %dx%d stride %d", who, d->kh, d->kw, d->stride);
+  PP_CHECK_ARG(ctx, d->cin > 0 && d->cout > 0 && (d->cin % 16 == 0 || d->cin == 4), PP_ERR_SHAPE,
+               "%s: cin %d must be a multiple of 16 (or 4 for the packed stem)", who, d->cin);
+  PP_CHECK_ARG(ctx, d->ld_w % 16 == 0 && d->ld_w >= d->cout, PP_ERR_SHAPE, "%s: ld_w %d (cout %d) must be a multiple of 16", who,
+               d->ld_w, d->cout);
+  PP_CHECK_ARG(ctx, d->ld_x % 4 == 0 && d->ld_x >= d->cin, PP_ERR_SHAPE, "%s: ld_x %d < cin %d or not a multiple of 4", who, d->ld_x, d->cin);
+  PP_CHECK_ARG(ctx, d->ld_y >= d->cout, PP_ERR_SHAPE, "%s: ld_y %d < cout %d", who, d->ld_y, d->cout);
+  PP_CHECK_ARG(ctx, d->pad_t >= 0 && d->pad_l >= 0 && d->pad_t < d->kh && d->pad_l < d->kw, PP_ERR_SHAPE, "%s: bad padding", who);
+  for (int s = 0; s < d->in.n_seg; ++s) {
+    // every output cell must lie inside the (bottom/right zero-extended) input: OH <= ceil((H + pad_t)/stride)
+    PP_CHECK_ARG(ctx, (d->out.h[s] - 1) * d->stride - d->pad_t < d->in.h[s] && (d->out.w[s] - 1) * d->stride - d->pad_l < d->in.w[s],
+                 PP_ERR_SHAPE, "%s: output %dx%d does not fit input %dx%d", who, d->out.h[s], d->out.w[s], d->in.h[s], d->in.w[s]);
+  }
+  if (d->in.n_seg > 1) PP_CHECK_ARG(ctx, d->stride == 1, PP_ERR_SHAPE, "%s: multi-level row spaces need stride 1", who);
+  return PP_OK;
+}
+
+template <int TM, int TN, bool BT, bool SMALLC>
+static void launch_igemm(hipStream_t st, IgemmParams& p) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  p.n_tiles_n = (p.Nout + BN - 1) / BN;
+  int n_tiles_m = (p.M + BM - 1) / BM;
+  hipLaunchKernelGGL((igemm_kernel<TM, TN, BT, SMALLC>), dim3((unsigned)(n_tiles_m * p.n_tiles_n)), dim3(256), 0, st, p);
+}
+
+extern "C" int pp_conv2d_nhwc_fwd(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const float* w, const float* bias,
+                                  const float* residual, int ld_res, int relu, float* y) {
+  PP_REQUIRE_CTX(ctx);
+  int rc = check_desc(ctx, d, "pp_conv2d_nhwc_fwd");
+  if (rc) return rc;
+  PP_CHECK_ARG(ctx, x && w && y, PP_ERR_ARG, "pp_conv2d_nhwc_fwd: null tensor");
+  PP_CHECK_ARG(ctx, pp_is_aligned16(x) && pp_is_aligned16(w) && pp_is_aligned16(y), PP_ERR_ALIGN,
+               "pp_conv2d_nhwc_fwd: tensors must be 16-byte aligned");
+  PP_CHECK_ARG(ctx, !residual || ld_res >= d->cout, PP_ERR_SHAPE, "pp_conv2d_nhwc_fwd: ld_res");
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.src = x; p.wgt = w; p.out = y; p.bias = bias; p.addend = residual; p.mask_src = nullptr;
+  p.ld_src = d->ld_x; p.ld_w = d->ld_w; p.ld_out = d->ld_y; p.ld_add = ld_res; p.ld_mask = 0;
+  p.relu = relu;
+  p.n_seg = d->in.n_seg;
+  fill_segs(ctx, d, true, p.seg, &p.M);
+  p.Cred = d->cin; p.Nout = d->cout; p.w_tap_rows = d->cin;
+  p.kh = d->kh; p.kw = d->kw;
+  p.mul = d->stride; p.tsign = 1; p.off_y = -d->pad_t; p.off_x = -d->pad_l; p.div = 1;
+  if (d->cin == 4) {
+    if (d->cout <= 64) launch_igemm<2, 1, false, true>(ctx->stream, p);
+    else launch_igemm<2, 2, false, true>(ctx->stream, p);
+  } else if (d->cout <= 64) {
+    launch_igemm<2, 1, false, false>(ctx->stream, p);
+  } else {
+    launch_igemm<2, 2, false, false>(ctx->stream, p);
+  }
+  PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_fwd");
+  return PP_OK;
+}
+
+extern "C" int pp_conv2d_nhwc_bwd_data(pp_ctx* ctx, const pp_conv_desc* d, const float* dy, const float* w, const float* addend,
+                                       int ld_add, const float* relu_src, int ld_rs, float* dx) {
+  PP_REQUIRE_CTX(ctx);
+  int rc = check_desc(ctx, d, "pp_conv2d_nhwc_bwd_data");
+  if (rc) return rc;
+  PP_CHECK_ARG(ctx, dy && w && dx, PP_ERR_ARG, "pp_conv2d_nhwc_bwd_data: null tensor");
+  PP_CHECK_ARG(ctx, d->cin % 16 == 0, PP_ERR_SHAPE, "pp_conv2d_nhwc_bwd_data: cin %d", d->cin);
+  const int cred = (d->cout + 15) / 16 * 16;
+  PP_CHECK_ARG(ctx, d->ld_y >= cred && d->ld_y % 4 == 0, PP_ERR_SHAPE,
+               "pp_conv2d_nhwc_bwd_data: dy needs ld_y >= %d (cout rounded up to 16, zero padded)", cred);
+  PP_CHECK_ARG(ctx, pp_is_aligned16(dy) && pp_is_aligned16(w) && pp_is_aligned16(dx), PP_ERR_ALIGN,
+               "pp_conv2d_nhwc_bwd_data: tensors must be 16-byte aligned");
+  PP_CHECK_ARG(ctx, (!addend || ld_add >= d->cin) && (!relu_src || ld_rs >= d->cin), PP_ERR_SHAPE, "pp_conv2d_nhwc_bwd_data: ld");
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.src = dy; p.wgt = w; p.out = dx; p.bias = nullptr; p.addend = addend; p.mask_src = relu_src;
+  p.ld_src = d->ld_y; p.ld_w = d->ld_w; p.ld_out = d->ld_x; p.ld_add = ld_add; p.ld_mask = ld_rs;
+  p.relu = 0;
+  p.n_seg = d->in.n_seg;
+  fill_segs(ctx, d, false, p.seg, &p.M);
+  p.Cred = cred; p.Nout = d->cin; p.w_tap_rows = d->cin;
+  p.kh = d->kh; p.kw = d->kw;
+  p.mul = 1; p.tsign = -1; p.off_y = d->pad_t; p.off_x = d->pad_l; p.div = d->stride;
+  if (d->cin <= 64) launch_igemm<2, 1, true, false>(ctx->stream, p);
+  else launch_igemm<2, 2, true, false>(ctx->stream, p);
+  PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_data");
+  return PP_OK;
+}
+
+template <int TM, int TN>
+static void launch_wgrad(pp_ctx* ctx, WgradParams& p) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  p.k_tiles_per_tap = p.Cin / BM;
+  p.n_tiles_k = p.kh * p.kw * p.k_tiles_per_tap;
+  p.n_tiles_n = (p.Cout + BN - 1) / BN;
+  const int tiles = p.n_tiles_k * p.n_tiles_n;
+  const int target = 4 * (ctx->n_cu > 0 ? ctx->n_cu : 256);
+  int splits = (target + tiles - 1) / tiles;
+  const int max_splits = (p.M + 255) / 256;  // at least 16 reduction steps per block
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int rps = (p.M + splits - 1) / splits;
+  rps = (rps + 15) / 16 * 16;
+  splits = (p.M + rps - 1) / rps;
+  p.splits = splits;
+  p.rows_per_split = rps;
+  hipLaunchKernelGGL((wgrad_kernel<TM, TN>), dim3((unsigned)(tiles * splits)), dim3(256), 0, ctx->stream, p);
+}
+
+extern "C" int pp_conv2d_nhwc_bwd_weight(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const float* dy, float* dw,
+                                         float* dbias) {
+  PP_REQUIRE_CTX(ctx);
+  int rc = check_desc(ctx, d, "pp_conv2d_nhwc_bwd_weight");
+  if (rc) return rc;
+  PP_CHECK_ARG(ctx, x && dy && dw, PP_ERR_ARG, "pp_conv2d_nhwc_bwd_weight: null tensor");
+  PP_CHECK_ARG(ctx, d->cin % 64 == 0, PP_ERR_SHAPE, "pp_conv2d_nhwc_bwd_weight: cin %d must be a multiple of 64", d->cin);
+  PP_CHECK_ARG(ctx, d->ld_y % 4 == 0, PP_ERR_SHAPE, "pp_conv2d_nhwc_bwd_weight: ld_y %d must be a multiple of 4", d->ld_y);
+  PP_CHECK_ARG(ctx, pp_is_aligned16(x) && pp_is_aligned16(dy), PP_ERR_ALIGN, "pp_conv2d_nhwc_bwd_weight: tensors must be 16-byte aligned");
+  WgradParams p;
+  memset(&p, 0, sizeof(p));
+  p.src = x; p.dy = dy; p.dw = dw; p.dbias = dbias;
+  p.ld_src = d->ld_x; p.ld_dy = d->ld_y; p.ld_w = d->ld_w;
+  p.n_seg = d->in.n_seg;
+  fill_segs(ctx, d, true, p.seg, &p.M);
+  p.Cin = d->cin; p.Cout = d->cout;
+  p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+  const bool big_k = (d->cin % 128 == 0);
+  const bool big_n = d->cout > 64;
+  if (big_k && big_n) launch_wgrad<2, 2>(ctx, p);
+  else if (big_k) launch_wgrad<2, 1>(ctx, p);
+  else if (big_n) launch_wgrad<1, 2>(ctx, p);
+  else launch_wgrad<1, 1>(ctx, p);
+  PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_weight");
+  return PP_OK;
+}

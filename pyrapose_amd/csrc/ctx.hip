@@ -1,0 +1,50 @@
+// Context management for libpyrapose_hip.so.
+#include <stdlib.h>
+
+#include "pp_internal.h"
+
+extern "C" const char* pp_version(void) { return "pyrapose_hip 0.1 (gfx950, f32-mfma)"; }
+
+extern "C" int pp_ctx_create(pp_ctx** out, int device, void* hip_stream) {
+  if (!out) return PP_ERR_ARG;
+  *out = nullptr;
+  int n_dev = 0;
+  hipError_t e = hipGetDeviceCount(&n_dev);
+  if (e != hipSuccess) return (int)e;
+  if (device < 0 || device >= n_dev) return PP_ERR_ARG;
+  pp_ctx* c = (pp_ctx*)calloc(1, sizeof(pp_ctx));
+  if (!c) return PP_ERR_ARG;
+  c->device = device;
+  c->stream = (hipStream_t)hip_stream;
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) {
+    free(c);
+    return (int)e;
+  }
+  c->n_cu = prop.multiProcessorCount;
+  snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
+  c->err[0] = 0;
+  *out = c;
+  return PP_OK;
+}
+
+extern "C" void pp_ctx_destroy(pp_ctx* ctx) { free(ctx); }
+
+extern "C" int pp_ctx_set_stream(pp_ctx* ctx, void* hip_stream) {
+  PP_REQUIRE_CTX(ctx);
+  ctx->stream = (hipStream_t)hip_stream;
+  return PP_OK;
+}
+
+extern "C" const char* pp_last_error_string(pp_ctx* ctx) { return ctx ? ctx->err : "no context"; }
+
+extern "C" int pp_device_info(pp_ctx* ctx, int* n_cu, char* name, int name_len) {
+  PP_REQUIRE_CTX(ctx);
+  if (n_cu) *n_cu = ctx->n_cu;
+  if (name && name_len > 0) {
+    strncpy(name, ctx->name, (size_t)name_len - 1);
+    name[name_len - 1] = 0;
+  }
+  return PP_OK;
+}

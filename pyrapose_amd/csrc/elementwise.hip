@@ -1,0 +1,222 @@
+// HBM-bound pointwise / resampling kernels of the PyraPose graph (float32, NHWC, 16 B per lane).
+#include "pp_internal.h"
+
+static inline unsigned grid_for(size_t n_items, int block, pp_ctx* ctx) {
+  size_t blocks = (n_items + block - 1) / block;
+  size_t cap = (size_t)(ctx->n_cu > 0 ? ctx->n_cu : 256) * 8;  // grid-stride beyond 8 blocks/CU
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+// ---- keras_resnet pool1: MaxPooling2D(3, strides=2, padding='same') --------------------------
+__global__ void maxpool3x3s2_kernel(int n_img, int h, int w, int c4, const float4* __restrict__ x, int oh, int ow,
+                                    int pad_t, int pad_l, float4* __restrict__ y) {
+  const size_t total = (size_t)n_img * oh * ow * c4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % c4);
+    size_t t = i / c4;
+    int ox = (int)(t % ow);
+    t /= ow;
+    int oy = (int)(t % oh);
+    int n = (int)(t / oh);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int dy = 0; dy < 3; ++dy) {
+      int iy = oy * 2 + dy - pad_t;
+      if ((unsigned)iy >= (unsigned)h) continue;
+      for (int dx = 0; dx < 3; ++dx) {
+        int ix = ox * 2 + dx - pad_l;
+        if ((unsigned)ix >= (unsigned)w) continue;
+        float4 v = x[((size_t)(n * h + iy) * w + ix) * c4 + c];
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    y[i] = m;
+  }
+}
+
+extern "C" int pp_maxpool3x3s2_fwd(pp_ctx* ctx, int n_img, int h, int w, int c, const float* x, int oh, int ow, float* y) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, x && y && n_img > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, PP_ERR_SHAPE, "pp_maxpool3x3s2_fwd: bad shape");
+  PP_CHECK_ARG(ctx, oh == (h + 1) / 2 && ow == (w + 1) / 2, PP_ERR_SHAPE, "pp_maxpool3x3s2_fwd: 'same' output must be ceil(in/2)");
+  // TF 'same': pad_total = max((out-1)*2 + 3 - in, 0), pad_before = pad_total / 2
+  int pt = ((oh - 1) * 2 + 3 - h); pt = pt > 0 ? pt / 2 : 0;
+  int pl = ((ow - 1) * 2 + 3 - w); pl = pl > 0 ? pl / 2 : 0;
+  size_t total = (size_t)n_img * oh * ow * (c / 4);
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total, 256, ctx)), dim3(256), 0, ctx->stream, n_img, h, w, c / 4,
+                     (const float4*)x, oh, ow, pt, pl, (float4*)y);
+  PP_CHECK_LAUNCH(ctx, "pp_maxpool3x3s2_fwd");
+  return PP_OK;
+}
+
+// ---- UpsampleLike (TF 2.1 tf.image.resize NEAREST, half-pixel centres) ------------------------
+__device__ __forceinline__ int nn_src(int dst, float scale, int n_in) {
+  int s = (int)floorf(((float)dst + 0.5f) * scale);
+  return s < n_in - 1 ? s : n_in - 1;
+}
+
+__global__ void upsample_add_fwd_kernel(int n_img, int sh, int sw, int th, int tw, int c4, float scale_y, float scale_x,
+                                        const float4* __restrict__ src, const float4* __restrict__ other,
+                                        float4* __restrict__ out) {
+  const size_t total = (size_t)n_img * th * tw * c4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % c4);
+    size_t t = i / c4;
+    int x = (int)(t % tw);
+    t /= tw;
+    int y = (int)(t % th);
+    int n = (int)(t / th);
+    int sy = nn_src(y, scale_y, sh), sx = nn_src(x, scale_x, sw);
+    float4 v = src[((size_t)(n * sh + sy) * sw + sx) * c4 + c];
+    if (other) {
+      float4 o = other[i];
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    out[i] = v;
+  }
+}
+
+__global__ void upsample_add_bwd_kernel(int n_img, int sh, int sw, int th, int tw, int c4, float scale_y, float scale_x,
+                                        float inv_y, float inv_x, const float4* __restrict__ dtarget,
+                                        const float4* __restrict__ base, float4* __restrict__ dsrc) {
+  const size_t total = (size_t)n_img * sh * sw * c4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % c4);
+    size_t t = i / c4;
+    int sx = (int)(t % sw);
+    t /= sw;
+    int sy = (int)(t % sh);
+    int n = (int)(t / sh);
+    float4 acc = base ? base[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    int y_lo = (int)(sy * inv_y) - 2, y_hi = (int)((sy + 1) * inv_y) + 2;
+    int x_lo = (int)(sx * inv_x) - 2, x_hi = (int)((sx + 1) * inv_x) + 2;
+    y_lo = y_lo < 0 ? 0 : y_lo; x_lo = x_lo < 0 ? 0 : x_lo;
+    y_hi = y_hi > th - 1 ? th - 1 : y_hi; x_hi = x_hi > tw - 1 ? tw - 1 : x_hi;
+    for (int y = y_lo; y <= y_hi; ++y) {
+      if (nn_src(y, scale_y, sh) != sy) continue;
+      for (int x = x_lo; x <= x_hi; ++x) {
+        if (nn_src(x, scale_x, sw) != sx) continue;
+        float4 g = dtarget[((size_t)(n * th + y) * tw + x) * c4 + c];
+        acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+      }
+    }
+    dsrc[i] = acc;
+  }
+}
+
+extern "C" int pp_upsample_nearest_add_fwd(pp_ctx* ctx, int n_img, int sh, int sw, int th, int tw, int c, const float* src,
+                                           const float* other, float* out) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, src && out && n_img > 0 && sh > 0 && sw > 0 && th > 0 && tw > 0 && c > 0 && c % 4 == 0, PP_ERR_SHAPE,
+               "pp_upsample_nearest_add_fwd: bad shape");
+  size_t total = (size_t)n_img * th * tw * (c / 4);
+  hipLaunchKernelGGL(upsample_add_fwd_kernel, dim3(grid_for(total, 256, ctx)), dim3(256), 0, ctx->stream, n_img, sh, sw, th, tw,
+                     c / 4, (float)sh / (float)th, (float)sw / (float)tw, (const float4*)src, (const float4*)other, (float4*)out);
+  PP_CHECK_LAUNCH(ctx, "pp_upsample_nearest_add_fwd");
+  return PP_OK;
+}
+
+extern "C" int pp_upsample_nearest_add_bwd(pp_ctx* ctx, int n_img, int sh, int sw, int th, int tw, int c, const float* dtarget,
+                                           const float* base, float* dsrc) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, dtarget && dsrc && n_img > 0 && sh > 0 && sw > 0 && th > 0 && tw > 0 && c > 0 && c % 4 == 0, PP_ERR_SHAPE,
+               "pp_upsample_nearest_add_bwd: bad shape");
+  size_t total = (size_t)n_img * sh * sw * (c / 4);
+  hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(grid_for(total, 256, ctx)), dim3(256), 0, ctx->stream, n_img, sh, sw, th, tw,
+                     c / 4, (float)sh / (float)th, (float)sw / (float)tw, (float)th / (float)sh, (float)tw / (float)sw,
+                     (const float4*)dtarget, (const float4*)base, (float4*)dsrc);
+  PP_CHECK_LAUNCH(ctx, "pp_upsample_nearest_add_bwd");
+  return PP_OK;
+}
+
+// ---- keras.layers.Add ---------------------------------------------------------------------------
+__global__ void add_n_kernel(size_t n4, const float4* __restrict__ a, const float4* __restrict__ b,
+                             const float4* __restrict__ c, float4* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 v = a[i];
+    if (b) { float4 w = b[i]; v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+    if (c) { float4 w = c[i]; v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+    out[i] = v;
+  }
+}
+
+extern "C" int pp_add_n(pp_ctx* ctx, size_t n, const float* a, const float* b, const float* c, float* out) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, a && out && n % 4 == 0, PP_ERR_SHAPE, "pp_add_n: n must be a multiple of 4");
+  if (n == 0) return PP_OK;
+  hipLaunchKernelGGL(add_n_kernel, dim3(grid_for(n / 4, 256, ctx)), dim3(256), 0, ctx->stream, n / 4, (const float4*)a,
+                     (const float4*)b, (const float4*)c, (float4*)out);
+  PP_CHECK_LAUNCH(ctx, "pp_add_n");
+  return PP_OK;
+}
+
+// ---- packed-RGB stem input ----------------------------------------------------------------------
+__global__ void pack_rgb4_kernel(size_t n_pix, const float* __restrict__ x3, float4* __restrict__ x4) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_pix; i += (size_t)gridDim.x * blockDim.x)
+    x4[i] = make_float4(x3[3 * i], x3[3 * i + 1], x3[3 * i + 2], 0.f);
+}
+
+extern "C" int pp_pack_rgb_to_4(pp_ctx* ctx, size_t n_pixels, const float* x3, float* x4) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, x3 && x4, PP_ERR_ARG, "pp_pack_rgb_to_4: null tensor");
+  if (n_pixels == 0) return PP_OK;
+  hipLaunchKernelGGL(pack_rgb4_kernel, dim3(grid_for(n_pixels, 256, ctx)), dim3(256), 0, ctx->stream, n_pixels, x3, (float4*)x4);
+  PP_CHECK_LAUNCH(ctx, "pp_pack_rgb_to_4");
+  return PP_OK;
+}
+
+// ---- head export: level-major [rows][ld] -> Keras (B, sum_l HW_l*A, V) ---------------------------
+struct ExportGeo {
+  int n_seg, n_img;
+  int row_begin[PP_MAX_SEG + 1];
+  int hw[PP_MAX_SEG];
+  int cell_off[PP_MAX_SEG];
+  int cells_total;
+};
+
+__global__ void export_head_kernel(ExportGeo g, int av, const float* __restrict__ src, int ld, int sig,
+                                   float* __restrict__ out) {
+  const size_t total = (size_t)g.row_begin[g.n_seg] * av;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int ch = (int)(i % av);
+    int m = (int)(i / av);
+    int s = 0;
+    for (int k = 1; k < g.n_seg; ++k)
+      if (m >= g.row_begin[k]) s = k;
+    int local = m - g.row_begin[s];
+    int b = local / g.hw[s];
+    int p = local - b * g.hw[s];
+    float v = src[(size_t)m * ld + ch];
+    if (sig) v = 1.f / (1.f + expf(-v));
+    out[((size_t)b * g.cells_total + g.cell_off[s] + p) * av + ch] = v;
+  }
+}
+
+static void fill_export_geo(const pp_rowspace* rs, ExportGeo* g) {
+  g->n_seg = rs->n_seg;
+  g->n_img = rs->n_img;
+  int rb = 0, co = 0;
+  for (int s = 0; s < rs->n_seg; ++s) {
+    g->row_begin[s] = rb;
+    g->hw[s] = rs->h[s] * rs->w[s];
+    g->cell_off[s] = co;
+    rb += rs->n_img * g->hw[s];
+    co += g->hw[s];
+  }
+  g->row_begin[rs->n_seg] = rb;
+  g->cells_total = co;
+}
+
+extern "C" int pp_export_head(pp_ctx* ctx, const pp_rowspace* rs, int n_anchor, int n_val, const float* src, int ld,
+                              int apply_sigmoid, float* out) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, rs && pp_rowspace_ok(rs) && src && out && n_anchor > 0 && n_val > 0 && ld >= n_anchor * n_val, PP_ERR_SHAPE,
+               "pp_export_head: bad shape");
+  ExportGeo g;
+  fill_export_geo(rs, &g);
+  size_t total = (size_t)g.row_begin[g.n_seg] * n_anchor * n_val;
+  hipLaunchKernelGGL(export_head_kernel, dim3(grid_for(total, 256, ctx)), dim3(256), 0, ctx->stream, g, n_anchor * n_val, src, ld,
+                     apply_sigmoid, out);
+  PP_CHECK_LAUNCH(ctx, "pp_export_head");
+  return PP_OK;
+}

@@ -1,0 +1,65 @@
+// Internal helpers shared by the HIP translation units of libpyrapose_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "pyrapose_hip.h"
+
+struct pp_ctx {
+  int device;
+  hipStream_t stream;
+  int n_cu;
+  char name[128];
+  char err[512];
+};
+
+static inline int pp_fail(pp_ctx* ctx, int code, const char* fmt, ...) {
+  if (ctx) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define PP_REQUIRE_CTX(ctx) \
+  do {                      \
+    if (!(ctx)) return PP_ERR_NOCTX; \
+  } while (0)
+
+#define PP_CHECK_ARG(ctx, cond, code, ...)            \
+  do {                                                \
+    if (!(cond)) return pp_fail(ctx, code, __VA_ARGS__); \
+  } while (0)
+
+// Launch-error check: hipGetLastError is not a synchronisation.
+#define PP_CHECK_LAUNCH(ctx, what)                                                   \
+  do {                                                                               \
+    hipError_t e__ = hipGetLastError();                                              \
+    if (e__ != hipSuccess)                                                           \
+      return pp_fail(ctx, (int)e__, "%s: launch failed: %s", what, hipGetErrorString(e__)); \
+  } while (0)
+
+#define PP_HIP(ctx, call)                                                                        \
+  do {                                                                                           \
+    hipError_t e__ = (call);                                                                     \
+    if (e__ != hipSuccess) return pp_fail(ctx, (int)e__, "%s: %s", #call, hipGetErrorString(e__)); \
+  } while (0)
+
+static inline long long pp_rowspace_rows(const pp_rowspace* rs) {
+  long long r = 0;
+  for (int s = 0; s < rs->n_seg; ++s) r += (long long)rs->n_img * rs->h[s] * rs->w[s];
+  return r;
+}
+
+static inline int pp_rowspace_ok(const pp_rowspace* rs) {
+  if (rs->n_img <= 0 || rs->n_seg <= 0 || rs->n_seg > PP_MAX_SEG) return 0;
+  for (int s = 0; s < rs->n_seg; ++s)
+    if (rs->h[s] <= 0 || rs->w[s] <= 0) return 0;
+  return pp_rowspace_rows(rs) < (1ll << 31);
+}
+
+static inline int pp_is_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

@@ -1,0 +1,467 @@
+"""Execution engine of the PyraPose hot path on one MI355X: builds the launch plan once for a fixed
+(batch, height, width, classes) and replays it.  Every FLOP runs in the HIP library; this file only
+owns buffers (torch tensors) and the order of C-ABI calls.
+
+Forward graph = reference models/resnet.py:79-110 + models/retinanet.py:180-214,224-229,296-299.
+Backward = reverse-mode over the same op list with the sum-of-consumers and the ReLU mask fused
+into the last data-gradient launch of each tensor (see DESIGN.md §Backward dataflow).
+Loss / optimizer = bin/train.py:95-102.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import arch, ops
+from ._lib import ParamDesc, RowSpace
+
+
+def _ru(v, m):
+    return (v + m - 1) // m * m
+
+
+def tf_same_pad(n_in, k, s):
+    out = -(-n_in // s)
+    total = max((out - 1) * s + k - n_in, 0)
+    return total // 2
+
+
+class Op(object):
+    """One C-ABI launch of the plan: `fn()` enqueues it on the ctx stream."""
+    __slots__ = ("fn", "kind", "name", "flops", "wrange")
+
+    def __init__(self, fn, kind, name="", flops=0.0, wrange=None):
+        self.fn, self.kind, self.name, self.flops, self.wrange = fn, kind, name, flops, wrange
+
+    def __call__(self):
+        self.fn()
+
+
+class Act(object):
+    """A level-major activation matrix [rows, ld] (see pp_rowspace)."""
+
+    def __init__(self, name, n_img, shapes, C, ld=None, t=None, needs_grad=False, relu=False):
+        self.name, self.n_img, self.shapes, self.C = name, n_img, list(shapes), C
+        self.ld = ld if ld is not None else C
+        self.rows = sum(n_img * h * w for h, w in self.shapes)
+        self.t = t if t is not None else torch.empty((self.rows, self.ld), dtype=torch.float32, device="cuda")
+        self.needs_grad, self.relu = needs_grad, relu
+        self.contribs = []
+
+    def rowspace(self):
+        return RowSpace.make(self.n_img, self.shapes)
+
+
+class ParamStore(object):
+    """Flat float32 parameter / gradient / Adam-state buffers + the table that cuts them into tensors."""
+
+    ALIGN = 64
+
+    def __init__(self, specs, train):
+        self.specs = OrderedDict((s.name, s) for s in specs)
+        self.entries = OrderedDict()  # key -> dict(offset, rows, ld, count, ...)
+        off = 0
+        soff = 0
+        for s in specs:
+            cin_eff = 4 if s.cin == 3 else s.cin
+            rows = _ru(s.k * s.k * cin_eff, 16)
+            ld = _ru(s.cout, 16)
+            self.entries[s.name + "/kernel"] = dict(offset=off, rows=rows, ld=ld, count=rows * ld, trainable=s.trainable,
+                                                    scale_off=(soff if s.bn else -1), l2=s.l2)
+            off = _ru(off + rows * ld, self.ALIGN)
+            # bias slot: the conv bias (trainable) or the frozen-BN shift
+            self.entries[s.name + "/bias"] = dict(offset=off, rows=1, ld=ld, count=ld, trainable=(s.bias and s.trainable),
+                                                  scale_off=-1, l2=0.0)
+            off = _ru(off + ld, self.ALIGN)
+            if s.bn:
+                soff += ld
+        self.total = off
+        self.n_scales = max(soff, 16)
+        z = lambda n: torch.zeros((n,), dtype=torch.float32, device="cuda")
+        self.w_master, self.w_eff = z(self.total), z(self.total)
+        self.scales = torch.ones((self.n_scales,), dtype=torch.float32, device="cuda")
+        self.train = train
+        if train:
+            self.grad, self.m, self.v = z(self.total), z(self.total), z(self.total)
+
+    def view(self, buf, key):
+        e = self.entries[key]
+        return buf[e["offset"]: e["offset"] + e["count"]].view(e["rows"], e["ld"])
+
+    def descs(self):
+        out = []
+        for key, e in self.entries.items():
+            d = ParamDesc()
+            d.offset, d.count, d.ld, d.trainable, d.scale_off, d.l2 = e["offset"], e["count"], e["ld"], int(e["trainable"]), e["scale_off"], e["l2"]
+            out.append(d)
+        return out
+
+    def load(self, W):
+        """W: dict in Keras layout (arch.init_weights).  Folds frozen BN into (scale, shift)."""
+        wm = np.zeros((self.total,), np.float32)
+        sc = np.ones((self.n_scales,), np.float32)
+        for name, s in self.specs.items():
+            ek, eb = self.entries[name + "/kernel"], self.entries[name + "/bias"]
+            k = np.asarray(W[name + "/kernel"], np.float32)
+            assert k.shape == (s.k, s.k, s.cin, s.cout), (name, k.shape)
+            if s.cin == 3:
+                k = np.concatenate([k, np.zeros((s.k, s.k, 1, s.cout), np.float32)], axis=2)
+            k2 = k.reshape(-1, s.cout)
+            buf = np.zeros((ek["rows"], ek["ld"]), np.float32)
+            buf[: k2.shape[0], : s.cout] = k2
+            wm[ek["offset"]: ek["offset"] + ek["count"]] = buf.reshape(-1)
+            b = np.zeros((eb["ld"],), np.float32)
+            if s.bn:
+                g, be = np.asarray(W[s.bn + "/gamma"], np.float64), np.asarray(W[s.bn + "/beta"], np.float64)
+                mu, var = np.asarray(W[s.bn + "/mean"], np.float64), np.asarray(W[s.bn + "/var"], np.float64)
+                scale = g / np.sqrt(var + arch.BN_EPS)
+                sc[ek["scale_off"]: ek["scale_off"] + s.cout] = scale.astype(np.float32)
+                b[: s.cout] = (be - mu * scale).astype(np.float32)
+            elif s.bias:
+                b[: s.cout] = np.asarray(W[name + "/bias"], np.float32)
+            wm[eb["offset"]: eb["offset"] + eb["count"]] = b
+        self._bn_raw = {k: np.asarray(v) for k, v in W.items() if k.split("/")[1] in ("gamma", "beta", "mean", "var")}
+        self.w_master.copy_(torch.from_numpy(wm))
+        self.scales.copy_(torch.from_numpy(sc))
+        self.refresh_eff()
+
+    def refresh_eff(self):
+        """w_eff = w_master * scale[co] for frozen-BN convs (host-driven; the optimizer does this on device)."""
+        self.w_eff.copy_(self.w_master)
+        for name, s in self.specs.items():
+            if s.bn:
+                ek = self.entries[name + "/kernel"]
+                sv = self.scales[ek["scale_off"]: ek["scale_off"] + ek["ld"]]
+                self.view(self.w_eff, name + "/kernel").mul_(sv.view(1, -1))
+
+    def export(self, buf=None):
+        """Back to the Keras-layout dict (kernels HWIO, biases; frozen BN statistics passed through)."""
+        buf = self.w_master if buf is None else buf
+        host = buf.detach().cpu().numpy()
+        W = OrderedDict()
+        for name, s in self.specs.items():
+            ek, eb = self.entries[name + "/kernel"], self.entries[name + "/bias"]
+            cin_eff = 4 if s.cin == 3 else s.cin
+            k = host[ek["offset"]: ek["offset"] + ek["count"]].reshape(ek["rows"], ek["ld"])[: s.k * s.k * cin_eff, : s.cout]
+            k = k.reshape(s.k, s.k, cin_eff, s.cout)[:, :, : s.cin, :]
+            W[name + "/kernel"] = np.ascontiguousarray(k)
+            if s.bias:
+                W[name + "/bias"] = host[eb["offset"]: eb["offset"] + s.cout].copy()
+        W.update(getattr(self, "_bn_raw", {}))
+        return W
+
+
+class Engine(object):
+    def __init__(self, ctx, num_classes, batch, height, width, backbone="resnet50", weights=None, train=True, seed=0,
+                 lr=1e-5, clipnorm=0.001):
+        self.ctx, self.C, self.B, self.H, self.W = ctx, int(num_classes), int(batch), int(height), int(width)
+        self.A = arch.NUM_ANCHORS
+        self.backbone = backbone
+        self.train = train
+        self.lr, self.clipnorm = lr, clipnorm
+        self.beta1, self.beta2, self.eps = 0.9, 0.999, 1e-7
+        self.specs = arch.all_specs(self.C, backbone)
+        self.params = ParamStore(self.specs, train)
+        self.params.load(weights if weights is not None else arch.init_weights(self.C, seed, backbone))
+        self.fwd_ops, self.graph_ops, self.bwd_ops = [], [], []
+        self.acts = OrderedDict()
+        self.step_count = 0
+        self._build_forward()
+        self.levels = arch.level_shapes(self.H, self.W)
+        assert [tuple(s) for s in self.pyr.shapes] == [tuple(s) for s in self.levels], (self.pyr.shapes, self.levels)
+        self.N = sum(h * w for h, w in self.levels) * self.A
+        self.M3 = self.levels[0][0] * self.levels[0][1]
+        f32 = dict(dtype=torch.float32, device="cuda")
+        self.out_box = torch.empty((self.B, self.N, 16), **f32)
+        self.out_cls = torch.empty((self.B, self.N, self.C), **f32)
+        self.out_mask = torch.empty((self.B, self.M3, self.C), **f32)
+        self.anchors_f32 = None
+        if train:
+            self.counts = torch.zeros((4,), dtype=torch.int32, device="cuda")
+            self.loss_sums = torch.zeros((4,), **f32)  # box, cls, mask, l2
+            self.gnorm_sq = torch.zeros((1,), **f32)
+            self.y_box = torch.zeros((self.B, self.N, 17), **f32)
+            self.y_cls = torch.zeros((self.B, self.N, self.C + 1), **f32)
+            self.y_mask = torch.zeros((self.B, self.M3, self.C + 1), **f32)
+            self.opt = ops.Optimizer(ctx, self.params.descs(), self.params.total)
+            self._build_backward()
+        self.grad_sync = None  # set by parallel.DataParallel
+
+    # ------------------------------------------------------------------------------------ forward plan
+    def _new_act(self, name, shapes, C, ld=None, needs_grad=False, relu=False, t=None):
+        a = Act(name, self.B, shapes, C, ld, t, needs_grad, relu)
+        self.acts[name] = a
+        return a
+
+    def _conv(self, spec_name, x, out_name=None, relu=False, residual=None, out_t=None, out_ld=None):
+        s = self.params.specs[spec_name]
+        k, st = s.k, s.stride
+        cin_eff = 4 if s.cin == 3 else s.cin
+        assert x.C == cin_eff, (spec_name, x.C, cin_eff)
+        out_shapes, pt, pl = [], 0, 0
+        for (h, w) in x.shapes:
+            if s.pad == "same":
+                oh, ow = -(-h // st), -(-w // st)
+                pt, pl = tf_same_pad(h, k, st), tf_same_pad(w, k, st)
+            else:
+                p = int(s.pad)
+                oh, ow = (h + 2 * p - k) // st + 1, (w + 2 * p - k) // st + 1
+                pt = pl = p
+            out_shapes.append((oh, ow))
+        ld_y = out_ld if out_ld is not None else _ru(s.cout, 16)
+        needs_grad = self.train and (s.trainable or x.needs_grad or (residual is not None and residual.needs_grad))
+        y = self._new_act(out_name or spec_name, out_shapes, s.cout, ld_y, needs_grad, relu, out_t)
+        ek = self.params.entries[spec_name + "/kernel"]
+        desc = ops.make_conv_desc(self.B, x.shapes, out_shapes, cin_eff, s.cout, k, st, pt, pl, x.ld, ld_y, ek["ld"])
+        w = self.params.view(self.params.w_eff, spec_name + "/kernel")
+        b = self.params.view(self.params.w_eff, spec_name + "/bias")
+        ctx = self.ctx
+        rt = residual.t if residual is not None else None
+        flops = 2.0 * y.rows * k * k * s.cin * s.cout
+        self.fwd_ops.append(Op(lambda: ops.conv_fwd(ctx, desc, x.t, w, b, rt, relu, y.t), "conv_fwd", spec_name, flops))
+        self.graph_ops.append(dict(kind="conv", spec=s, x=x, y=y, residual=residual, desc=desc, w=w, flops=flops))
+        return y
+
+    def _build_forward(self):
+        B, H, W = self.B, self.H, self.W
+        ctx = self.ctx
+        self.x_in = torch.zeros((B, H, W, 3), dtype=torch.float32, device="cuda")
+        x4 = self._new_act("input4", [(H, W)], 4)
+        self.fwd_ops.append(Op(lambda: ops.pack_rgb_to_4(ctx, self.x_in, x4.t), "pointwise", "pack_rgb"))
+        y = self._conv("conv1", x4, relu=True)
+        (h1, w1) = y.shapes[0]
+        ph, pw = (h1 + 1) // 2, (w1 + 1) // 2
+        pool = self._new_act("pool1", [(ph, pw)], 64)
+        c1 = y
+        self.fwd_ops.append(Op(lambda: ops.maxpool3x3s2(ctx, B, h1, w1, 64, c1.t, ph, pw, pool.t), "pointwise", "pool1"))
+        self.graph_ops.append(dict(kind="stop"))
+        y = pool
+        blocks = arch.BACKBONE_BLOCKS[self.backbone]
+        numerical = {"resnet50": [False] * 4, "resnet101": [False, True, True, False], "resnet152": [False, True, True, False]}[self.backbone]
+        stage_out = []
+        for stage, n_blocks in enumerate(blocks):
+            for block in range(n_blocks):
+                pre = "res%d%s" % (stage + 2, arch.block_name(stage, block, numerical[stage]))
+                a = self._conv(pre + "_branch2a", y, relu=True)
+                b = self._conv(pre + "_branch2b", a, relu=True)
+                sc = self._conv(pre + "_branch1", y) if block == 0 else y
+                y = self._conv(pre + "_branch2c", b, out_name=pre, relu=True, residual=sc)
+            stage_out.append(y)
+        C3, C4, C5 = stage_out[1], stage_out[2], stage_out[3]
+        self.C3, self.C4, self.C5 = C3, C4, C5
+        # ---- __create_sparceFPN (models/retinanet.py:180-214)
+        L3 = self._conv("fpn_lat3", C3)
+        L4 = self._conv("fpn_lat4", C4)
+        L5 = self._conv("fpn_lat5", C5)
+        S4 = self._upadd("fpn_sum4", L5, L4)
+        S3 = self._upadd("fpn_sum3", L4, L3)
+        M4 = self._conv("fpn_mid4", S4)
+        M3 = self._conv("fpn_mid3", S3)
+        D3 = self._conv("fpn_down3", M3)
+        F3 = self._add("fpn_fin3", [M3, L3])
+        # pyramid buffer: P3 | P4 | P5 rows, so that the shared heads run as ONE multi-level launch
+        lv = [L3.shapes[0], L4.shapes[0], L5.shapes[0]]
+        rows = [B * h * w for h, w in lv]
+        pyr_t = torch.empty((sum(rows), 256), dtype=torch.float32, device="cuda")
+        sl = [pyr_t[0: rows[0]], pyr_t[rows[0]: rows[0] + rows[1]], pyr_t[rows[0] + rows[1]:]]
+        P3 = self._conv("P3", F3, out_t=sl[0])
+        F4 = self._add("fpn_fin4", [D3, M4, L4])
+        D4 = self._conv("fpn_down4", M4)
+        P4 = self._conv("P4", F4, out_t=sl[1])
+        F5 = self._add("fpn_fin5", [D4, L5])
+        P5 = self._conv("P5", F5, out_t=sl[2])
+        needs = self.train
+        pyr = self._new_act("pyramid", lv, 256, 256, needs, False, pyr_t)
+        self.graph_ops.append(dict(kind="alias", y=pyr, parts=[P3, P4, P5], rows=rows))
+        self.pyr, self.P3 = pyr, P3
+        # ---- heads (models/retinanet.py:9-131, shared across levels :224-225; mask on P3 only :296)
+        def run_head(prefix, feat):
+            y = feat
+            for i in range(4):
+                y = self._conv("%s_conv%d" % (prefix, i), y, relu=True)
+            return self._conv(prefix + "_out", y)
+        self.reg_out = run_head("reg", pyr)
+        self.cls_out = run_head("cls", pyr)
+        self.mask_out = run_head("mask", P3)
+
+    def _upadd(self, name, src, other):
+        (sh, sw), (th, tw) = src.shapes[0], other.shapes[0]
+        out = self._new_act(name, [(th, tw)], src.C, src.ld, src.needs_grad or other.needs_grad)
+        ctx, B = self.ctx, self.B
+        self.fwd_ops.append(Op(lambda: ops.upsample_add_fwd(ctx, B, sh, sw, th, tw, src.C, src.t, other.t, out.t), "pointwise", name))
+        self.graph_ops.append(dict(kind="upadd", y=out, src=src, other=other))
+        return out
+
+    def _add(self, name, ins):
+        out = self._new_act(name, ins[0].shapes, ins[0].C, ins[0].ld, any(i.needs_grad for i in ins))
+        ctx = self.ctx
+        a, b, c = ins[0].t, ins[1].t, (ins[2].t if len(ins) > 2 else None)
+        self.fwd_ops.append(Op(lambda: ops.add_n(ctx, a, b, c, out.t), "pointwise", name))
+        self.graph_ops.append(dict(kind="add", y=out, ins=ins))
+        return out
+
+    # ------------------------------------------------------------------------------------ backward plan
+    def _finalize(self, act):
+        """Sum the gradient contributions of `act`; the ReLU mask (act > 0) is folded into the last
+        data-gradient launch.  Returns the gradient w.r.t. the pre-activation, or None."""
+        ctx = self.ctx
+        tensors = [c[1] for c in act.contribs if c[0] == "tensor"]
+        dgrads = [c for c in act.contribs if c[0] == "dgrad"]
+        if not tensors and not dgrads:
+            return None
+        new = lambda: torch.empty((act.rows, act.ld), dtype=torch.float32, device="cuda")
+        acc = None
+        if len(tensors) == 1:
+            acc = tensors[0]
+        elif len(tensors) > 1:
+            acc = new()
+            srcs, rest = tensors[:3], tensors[3:]
+            while True:
+                a, b, c = srcs[0], (srcs[1] if len(srcs) > 1 else None), (srcs[2] if len(srcs) > 2 else None)
+                self.bwd_ops.append(Op(lambda a=a, b=b, c=c, out=acc: ops.add_n(ctx, a, b, c, out), "pointwise", "add:" + act.name))
+                if not rest:
+                    break
+                srcs, rest = [acc] + rest[:2], rest[2:]  # in-place accumulate (pointwise: safe)
+        if act.relu and not dgrads:
+            raise NotImplementedError("relu output %s without a data-gradient consumer" % act.name)
+        for i, (_, op, gy) in enumerate(dgrads):
+            last = i == len(dgrads) - 1
+            out = new()
+            mask = act.t if (act.relu and last) else None
+            self.bwd_ops.append(Op(lambda d=op["desc"], gy=gy, w=op["w"], acc=acc, mask=mask, out=out:
+                                   ops.conv_bwd_data(ctx, d, gy, w, acc, mask, out), "conv_dgrad", op["spec"].name, op["flops"]))
+            acc = out
+        return acc
+
+    def _build_backward(self):
+        ctx, P = self.ctx, self.params
+        f32 = dict(dtype=torch.float32, device="cuda")
+        self.g_reg = torch.zeros((self.reg_out.rows, self.reg_out.ld), **f32)
+        self.g_cls = torch.zeros((self.cls_out.rows, self.cls_out.ld), **f32)
+        self.g_mask = torch.zeros((self.mask_out.rows, self.mask_out.ld), **f32)
+        self.reg_out.contribs.append(("tensor", self.g_reg))
+        self.cls_out.contribs.append(("tensor", self.g_cls))
+        self.mask_out.contribs.append(("tensor", self.g_mask))
+        for op in reversed(self.graph_ops):
+            kind = op["kind"]
+            if kind == "stop":
+                break
+            y = op["y"]
+            if not y.needs_grad:
+                continue
+            g = self._finalize(y)
+            if g is None:
+                continue
+            if kind == "conv":
+                s, x = op["spec"], op["x"]
+                if s.trainable:
+                    dw = P.view(P.grad, s.name + "/kernel")
+                    db = P.view(P.grad, s.name + "/bias") if s.bias else None
+                    ek = P.entries[s.name + "/kernel"]
+                    eb = P.entries[s.name + "/bias"]
+                    wr = (ek["offset"], eb["offset"] + eb["count"])
+                    self.bwd_ops.append(Op(lambda d=op["desc"], xt=x.t, g=g, dw=dw, db=db: ops.conv_bwd_weight(ctx, d, xt, g, dw, db),
+                                           "conv_wgrad", s.name, op["flops"], wr))
+                if x.needs_grad:
+                    x.contribs.append(("dgrad", op, g))
+                r = op["residual"]
+                if r is not None and r.needs_grad:
+                    r.contribs.append(("tensor", g))
+            elif kind == "add":
+                for i in op["ins"]:
+                    if i.needs_grad:
+                        i.contribs.append(("tensor", g))
+            elif kind == "upadd":
+                src, other = op["src"], op["other"]
+                if other.needs_grad:
+                    other.contribs.append(("tensor", g))
+                if src.needs_grad:
+                    gs = torch.empty((src.rows, src.ld), **f32)
+                    (sh, sw), (th, tw) = src.shapes[0], other.shapes[0]
+                    self.bwd_ops.append(Op(lambda g=g, gs=gs, sh=sh, sw=sw, th=th, tw=tw, c=src.C:
+                                           ops.upsample_add_bwd(ctx, self.B, sh, sw, th, tw, c, g, None, gs), "pointwise", "upbwd:" + src.name))
+                    src.contribs.append(("tensor", gs))
+            elif kind == "alias":
+                r0 = 0
+                for part, n in zip(op["parts"], op["rows"]):
+                    part.contribs.append(("tensor", g[r0: r0 + n]))
+                    r0 += n
+
+    # ------------------------------------------------------------------------------------ execution
+    def forward(self, x=None):
+        if x is not None:
+            self.x_in.copy_(x)
+        for f in self.fwd_ops:
+            f()
+
+    def export_outputs(self):
+        """Keras prediction-model outputs (models/retinanet.py:302-335): [boxes3D, cls probs, mask probs]."""
+        ctx = self.ctx
+        ops.export_head(ctx, self.pyr.rowspace(), self.A, 16, self.reg_out.t, False, self.out_box)
+        ops.export_head(ctx, self.pyr.rowspace(), self.A, self.C, self.cls_out.t, True, self.out_cls)
+        ops.export_head(ctx, self.P3.rowspace(), 1, self.C, self.mask_out.t, True, self.out_mask)
+        return self.out_box, self.out_cls, self.out_mask
+
+    def anchors_device_f32(self):
+        if self.anchors_f32 is None:
+            from .utils import anchors as ua
+            p = ua.AnchorParameters.default
+            base = np.stack([ops.generate_base_anchors(sz, p.ratios, p.scales) for sz in p.sizes[: len(self.levels)]])
+            self.anchors_f32 = ops.anchors_shift(self.ctx, self.levels, p.strides[: len(self.levels)], base, torch.float32)
+        return self.anchors_f32
+
+    def predict_on_batch(self, x):
+        """-> (boxes3D (B,N,16), scores (B,N,C), mask (B,HW/64,C)) device tensors."""
+        self.forward(x)
+        reg, cls, mask = self.export_outputs()
+        boxes3d = ops.box3d_decode(self.ctx, self.anchors_device_f32(), reg)
+        return boxes3d, cls, mask
+
+    def set_targets(self, y_box, y_cls, y_mask):
+        self.y_box.copy_(y_box)
+        self.y_cls.copy_(y_cls)
+        self.y_mask.copy_(y_mask)
+
+    def loss_and_backward(self):
+        """Counts -> (DP: global counts) -> fused loss fwd+bwd -> backward plan.  Leaves gradients in params.grad."""
+        ctx, P = self.ctx, self.params
+        P.grad.zero_()
+        self.counts.zero_()
+        self.loss_sums.zero_()
+        ops.count_positives(ctx, self.y_box, self.y_cls, self.y_mask, self.counts)
+        if self.grad_sync is not None:
+            self.grad_sync.reduce_counts(self.counts)
+        ops.orth_l1(ctx, self.pyr.rowspace(), self.A, self.reg_out.t, self.y_box, 0.125, 3.0, self.counts[0:1], 1.0,
+                    self.loss_sums[0:1], self.g_reg)
+        ops.focal(ctx, self.pyr.rowspace(), self.A, self.C, self.cls_out.t, self.y_cls, 0.25, 2.0, self.counts[1:2], 1.0,
+                  self.loss_sums[1:2], self.g_cls)
+        ops.focal(ctx, self.P3.rowspace(), 1, self.C, self.mask_out.t, self.y_mask, 0.25, 2.0, self.counts[2:3], 1.0,
+                  self.loss_sums[2:3], self.g_mask)
+        sync = self.grad_sync
+        for i, op in enumerate(self.bwd_ops):
+            op()
+            if sync is not None:
+                sync.after_bwd_op(i)
+
+    def optimizer_step(self):
+        P = self.params
+        self.step_count += 1
+        self.opt.grad_norm(P.w_master, P.grad, P.scales, self.gnorm_sq, self.loss_sums[3:4])
+        self.opt.adam_step(P.w_master, P.w_eff, P.grad, P.scales, P.m, P.v, self.gnorm_sq, self.lr, self.beta1, self.beta2,
+                           self.eps, self.clipnorm, self.step_count)
+
+    def train_step(self, x=None, targets=None):
+        """One optimisation step (Keras train_on_batch): fwd + losses + bwd + clipnorm-Adam.  Returns nothing;
+        read `losses()` afterwards (a device->host copy) when the values are wanted."""
+        if targets is not None:
+            self.set_targets(*targets)
+        self.forward(x)
+        self.loss_and_backward()
+        if self.grad_sync is not None:
+            self.grad_sync.finish()
+        self.optimizer_step()
+
+    def losses(self):
+        v = self.loss_sums.detach().cpu().numpy()
+        return {"3Dbox": float(v[0]), "cls": float(v[1]), "mask": float(v[2]), "l2": float(v[3]), "total": float(v.sum())}

@@ -1,0 +1,254 @@
+"""Thin torch-tensor wrappers over the C ABI (include/pyrapose_hip.h).
+
+Every function takes CUDA(ROCm) float32/float64/int tensors, hands raw device pointers to the HIP
+library on the ctx stream, and raises on a non-zero status.  torch is used only for memory and streams.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, ParamDesc, RowSpace, check, lib
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "pyrapose_amd ops need device tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """One per (process, device, stream): wraps pp_ctx."""
+
+    def __init__(self, device=0, stream=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("pyrapose_amd: no GPU visible (torch.cuda.is_available() is False); "
+                               "the HIP path has no CPU fallback")
+        self.device = int(device)
+        torch.cuda.set_device(self.device)
+        self.handle = C.c_void_p()
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self.stream = s
+        check(lib.pp_ctx_create(C.byref(self.handle), self.device, C.c_void_p(s.cuda_stream)), None, "pp_ctx_create")
+
+    def use_stream(self, stream):
+        self.stream = stream
+        check(lib.pp_ctx_set_stream(self.handle, C.c_void_p(stream.cuda_stream)), self.handle, "pp_ctx_set_stream")
+
+    def device_info(self):
+        n = C.c_int(0)
+        buf = C.create_string_buffer(128)
+        check(lib.pp_device_info(self.handle, C.byref(n), buf, 128), self.handle)
+        return n.value, buf.value.decode()
+
+    def close(self):
+        if self.handle:
+            lib.pp_ctx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+def make_conv_desc(n_img, in_shapes, out_shapes, cin, cout, k, stride, pad_t, pad_l, ld_x, ld_y, ld_w):
+    d = ConvDesc()
+    d.in_ = RowSpace.make(n_img, in_shapes)
+    d.out = RowSpace.make(n_img, out_shapes)
+    d.cin, d.cout, d.kh, d.kw, d.stride = cin, cout, k, k, stride
+    d.pad_t, d.pad_l, d.ld_x, d.ld_y, d.ld_w = pad_t, pad_l, ld_x, ld_y, ld_w
+    return d
+
+
+def conv_fwd(ctx, d, x, w, bias, residual, relu, y):
+    ld_res = residual.stride(0) if residual is not None else 0
+    check(lib.pp_conv2d_nhwc_fwd(ctx.handle, C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), ld_res,
+                                 int(bool(relu)), _ptr(y)), ctx.handle, "pp_conv2d_nhwc_fwd")
+
+
+def conv_bwd_data(ctx, d, dy, w, addend, relu_src, dx):
+    ld_add = addend.stride(0) if addend is not None else 0
+    ld_rs = relu_src.stride(0) if relu_src is not None else 0
+    check(lib.pp_conv2d_nhwc_bwd_data(ctx.handle, C.byref(d), _ptr(dy), _ptr(w), _ptr(addend), ld_add, _ptr(relu_src),
+                                      ld_rs, _ptr(dx)), ctx.handle, "pp_conv2d_nhwc_bwd_data")
+
+
+def conv_bwd_weight(ctx, d, x, dy, dw, dbias):
+    check(lib.pp_conv2d_nhwc_bwd_weight(ctx.handle, C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(dbias)), ctx.handle,
+          "pp_conv2d_nhwc_bwd_weight")
+
+
+def maxpool3x3s2(ctx, n_img, h, w, c, x, oh, ow, y):
+    check(lib.pp_maxpool3x3s2_fwd(ctx.handle, n_img, h, w, c, _ptr(x), oh, ow, _ptr(y)), ctx.handle, "pp_maxpool3x3s2_fwd")
+
+
+def upsample_add_fwd(ctx, n_img, sh, sw, th, tw, c, src, other, out):
+    check(lib.pp_upsample_nearest_add_fwd(ctx.handle, n_img, sh, sw, th, tw, c, _ptr(src), _ptr(other), _ptr(out)),
+          ctx.handle, "pp_upsample_nearest_add_fwd")
+
+
+def upsample_add_bwd(ctx, n_img, sh, sw, th, tw, c, dtarget, base, dsrc):
+    check(lib.pp_upsample_nearest_add_bwd(ctx.handle, n_img, sh, sw, th, tw, c, _ptr(dtarget), _ptr(base), _ptr(dsrc)),
+          ctx.handle, "pp_upsample_nearest_add_bwd")
+
+
+def add_n(ctx, a, b, c, out):
+    check(lib.pp_add_n(ctx.handle, a.numel(), _ptr(a), _ptr(b), _ptr(c), _ptr(out)), ctx.handle, "pp_add_n")
+
+
+def pack_rgb_to_4(ctx, x3, x4):
+    check(lib.pp_pack_rgb_to_4(ctx.handle, x3.numel() // 3, _ptr(x3), _ptr(x4)), ctx.handle, "pp_pack_rgb_to_4")
+
+
+def export_head(ctx, rs, n_anchor, n_val, src, apply_sigmoid, out):
+    check(lib.pp_export_head(ctx.handle, C.byref(rs), n_anchor, n_val, _ptr(src), src.stride(0), int(apply_sigmoid), _ptr(out)),
+          ctx.handle, "pp_export_head")
+
+
+def count_positives(ctx, y_box, y_cls, y_mask, counts):
+    rb = y_box.shape[0] * y_box.shape[1] if y_box is not None else 0
+    rc = y_cls.shape[0] * y_cls.shape[1] if y_cls is not None else 0
+    rm = y_mask.shape[0] * y_mask.shape[1] if y_mask is not None else 0
+    cc = y_cls.shape[2] - 1 if y_cls is not None else 0
+    cm = y_mask.shape[2] - 1 if y_mask is not None else 0
+    check(lib.pp_count_positives(ctx.handle, rb, _ptr(y_box), rc, cc, _ptr(y_cls), rm, cm, _ptr(y_mask), _ptr(counts)),
+          ctx.handle, "pp_count_positives")
+
+
+def focal(ctx, rs, n_anchor, n_class, logits, y_true, alpha, gamma, count, loss_weight, loss_sum, dlogits):
+    check(lib.pp_sigmoid_focal_fwd_bwd(ctx.handle, C.byref(rs), n_anchor, n_class, _ptr(logits), logits.stride(0),
+                                       _ptr(y_true), alpha, gamma, _ptr(count), loss_weight, _ptr(loss_sum), _ptr(dlogits)),
+          ctx.handle, "pp_sigmoid_focal_fwd_bwd")
+
+
+def orth_l1(ctx, rs, n_anchor, pred, y_true, weight, sigma, count, loss_weight, loss_sum, dpred):
+    check(lib.pp_orth_smoothl1_fwd_bwd(ctx.handle, C.byref(rs), n_anchor, _ptr(pred), pred.stride(0), _ptr(y_true), weight,
+                                       sigma, _ptr(count), loss_weight, _ptr(loss_sum), _ptr(dpred)),
+          ctx.handle, "pp_orth_smoothl1_fwd_bwd")
+
+
+class Optimizer:
+    def __init__(self, ctx, descs, total):
+        arr = (ParamDesc * len(descs))(*descs)
+        self.handle = C.c_void_p()
+        self.ctx = ctx
+        check(lib.pp_optimizer_create(ctx.handle, C.byref(self.handle), arr, len(descs), total), ctx.handle,
+              "pp_optimizer_create")
+
+    def grad_norm(self, w_master, g_eff, scales, gnorm_sq, l2_loss=None):
+        check(lib.pp_grad_global_norm(self.ctx.handle, self.handle, _ptr(w_master), _ptr(g_eff), _ptr(scales),
+                                      _ptr(gnorm_sq), _ptr(l2_loss)), self.ctx.handle, "pp_grad_global_norm")
+
+    def adam_step(self, w_master, w_eff, g_eff, scales, m, v, gnorm_sq, lr, beta1, beta2, eps, clipnorm, step):
+        check(lib.pp_adam_step_clipnorm(self.ctx.handle, self.handle, _ptr(w_master), _ptr(w_eff), _ptr(g_eff), _ptr(scales),
+                                        _ptr(m), _ptr(v), _ptr(gnorm_sq), lr, beta1, beta2, eps, clipnorm, int(step)),
+              self.ctx.handle, "pp_adam_step_clipnorm")
+
+    def close(self):
+        if self.handle:
+            lib.pp_optimizer_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+# ---- anchors / targets / decode -------------------------------------------------------------------
+def _iarr(v):
+    return (C.c_int * len(v))(*[int(x) for x in v])
+
+
+def generate_base_anchors(base_size, ratios, scales):
+    r = np.ascontiguousarray(ratios, np.float32)
+    s = np.ascontiguousarray(scales, np.float32)
+    out = np.empty((len(r) * len(s), 4), np.float64)
+    check(lib.pp_generate_base_anchors_host(int(base_size), r.ctypes.data_as(C.POINTER(C.c_float)), len(r),
+                                            s.ctypes.data_as(C.POINTER(C.c_float)), len(s),
+                                            out.ctypes.data_as(C.POINTER(C.c_double))), None, "pp_generate_base_anchors_host")
+    return out
+
+
+def anchors_shift(ctx, feat_shapes, strides, base_anchors, dtype=torch.float64):
+    """feat_shapes: [(h, w)] per level; base_anchors: float64 [L, A, 4] (numpy)."""
+    base = np.ascontiguousarray(base_anchors, np.float64)
+    L, A = base.shape[0], base.shape[1]
+    n = sum(h * w for h, w in feat_shapes) * A
+    out = torch.empty((n, 4), dtype=dtype, device="cuda")
+    fn = lib.pp_anchors_shift_f64 if dtype == torch.float64 else lib.pp_anchors_shift_f32
+    check(fn(ctx.handle, L, _iarr([h for h, _ in feat_shapes]), _iarr([w for _, w in feat_shapes]), _iarr(strides), A,
+             base.ctypes.data_as(C.POINTER(C.c_double)), _ptr(out)), ctx.handle, "pp_anchors_shift")
+    return out
+
+
+def compute_overlap(ctx, boxes, query):
+    n, k = boxes.shape[0], query.shape[0]
+    out = torch.zeros((n, k), dtype=torch.float64, device="cuda")
+    check(lib.pp_compute_overlap_f64(ctx.handle, n, _ptr(boxes), k, _ptr(query), _ptr(out)), ctx.handle, "pp_compute_overlap_f64")
+    return out
+
+
+def compute_gt_annotations(ctx, anchors, gt, neg=0.4, pos=0.5):
+    n, k = anchors.shape[0], gt.shape[0]
+    argmax = torch.empty((n,), dtype=torch.int32, device="cuda")
+    state = torch.empty((n,), dtype=torch.int8, device="cuda")
+    check(lib.pp_compute_gt_annotations(ctx.handle, n, _ptr(anchors), k, _ptr(gt), neg, pos, _ptr(argmax), _ptr(state)),
+          ctx.handle, "pp_compute_gt_annotations")
+    return argmax, state
+
+
+def project_box3d(pose7, box8x3, cam4):
+    p = np.ascontiguousarray(pose7, np.float64)
+    b = np.ascontiguousarray(box8x3, np.float64)
+    c = np.ascontiguousarray(cam4, np.float64)
+    out = np.empty(16, np.float64)
+    dp = C.POINTER(C.c_double)
+    check(lib.pp_project_box3d_host(p.ctypes.data_as(dp), b.ctypes.data_as(dp), c.ctypes.data_as(dp), out.ctypes.data_as(dp)),
+          None, "pp_project_box3d_host")
+    return out
+
+
+def pil_nearest_index(n_in, n_out):
+    out = np.empty(n_out, np.int32)
+    check(lib.pp_pil_nearest_index_host(n_in, n_out, out.ctypes.data_as(C.POINTER(C.c_int))), None, "pp_pil_nearest_index_host")
+    return out
+
+
+def anchor_targets(ctx, anchors, gt_offset, gt_boxes, gt_labels, gt_box3d, gt_mask_ids, id_masks, mask_hw, image_hw,
+                   num_classes, out_mh, out_mw, neg=0.4, pos=0.5):
+    """anchors: cuda f64 [N,4]; gt_* cuda tensors packed over the batch; id_masks cuda uint8 [B,H,W] or None."""
+    B = len(gt_offset) - 1
+    N = anchors.shape[0]
+    reg = torch.empty((B, N, 17), dtype=torch.float32, device="cuda")
+    lab = torch.empty((B, N, num_classes + 1), dtype=torch.float32, device="cuda")
+    msk = torch.empty((B, out_mh * out_mw, num_classes + 1), dtype=torch.float32, device="cuda")
+    mh, mw = (id_masks.shape[1], id_masks.shape[2]) if id_masks is not None else (0, 0)
+    check(lib.pp_anchor_targets(ctx.handle, N, _ptr(anchors), B, _iarr(gt_offset), _ptr(gt_boxes), _ptr(gt_labels),
+                                _ptr(gt_box3d), _ptr(gt_mask_ids), _ptr(id_masks), mh, mw,
+                                _iarr(np.asarray(mask_hw).reshape(-1)) if mask_hw is not None else None,
+                                _iarr(np.asarray(image_hw).reshape(-1)), num_classes, neg, pos, out_mh, out_mw,
+                                _ptr(reg), _ptr(lab), _ptr(msk)), ctx.handle, "pp_anchor_targets")
+    return reg, lab, msk
+
+
+def box3d_decode(ctx, anchors_f32, regression):
+    B, N = regression.shape[0], regression.shape[1]
+    out = torch.empty_like(regression)
+    check(lib.pp_box3d_decode(ctx.handle, B, N, _ptr(anchors_f32), _ptr(regression), _ptr(out)), ctx.handle, "pp_box3d_decode")
+    return out
+
+
+def score_threshold_compact(ctx, scores, thr=0.5, cap=None):
+    B, N, Cc = scores.shape
+    cap = int(cap or N)
+    idx = torch.empty((B, Cc, cap), dtype=torch.int32, device="cuda")
+    cnt = torch.empty((B, Cc), dtype=torch.int32, device="cuda")
+    check(lib.pp_score_threshold_compact(ctx.handle, B, N, Cc, _ptr(scores), thr, cap, _ptr(idx), _ptr(cnt)), ctx.handle,
+          "pp_score_threshold_compact")
+    return idx, cnt
+
+
+def filter_detections(ctx, boxes, boxes3d, scores, score_thr=0.05, iou_thr=0.5, max_det=300):
+    N, Cc = scores.shape
+    ws = torch.empty((lib.pp_filter_workspace_bytes(N, Cc, max_det),), dtype=torch.uint8, device="cuda")
+    ob = torch.empty((max_det, 4), dtype=torch.float32, device="cuda")
+    o3 = torch.empty((max_det, 16), dtype=torch.float32, device="cuda")
+    osc = torch.empty((max_det,), dtype=torch.float32, device="cuda")
+    ol = torch.empty((max_det,), dtype=torch.int32, device="cuda")
+    check(lib.pp_filter_detections(ctx.handle, N, Cc, _ptr(boxes), _ptr(boxes3d), _ptr(scores), score_thr, iou_thr, max_det,
+                                   _ptr(ws), _ptr(ob), _ptr(o3), _ptr(osc), _ptr(ol)), ctx.handle, "pp_filter_detections")
+    return ob, o3, osc, ol

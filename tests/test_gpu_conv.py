@@ -1,0 +1,224 @@
+"""GPU: the implicit-GEMM MFMA convolution family (fwd / bwd-data / bwd-weight) through the C ABI
+against a plain PyTorch-CPU float64 reference of the same op.  Tolerance: 2e-5 relative to the
+output's max magnitude (the kernels are exact-f32 fma chains; the north star allows 1e-3)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from pyrapose_amd import ops
+    return ops.Context(0)
+
+
+def tf_same(n, k, s):
+    out = -(-n // s)
+    tot = max((out - 1) * s + k - n, 0)
+    return tot // 2, tot - tot // 2, out
+
+
+def ref_conv(x_list, w_hwio, bias, stride, pad):
+    """x_list: per level NHWC float64 tensors.  Returns per-level NHWC outputs."""
+    w = torch.as_tensor(w_hwio, dtype=torch.float64).permute(3, 2, 0, 1)
+    outs = []
+    for x in x_list:
+        xt = x.permute(0, 3, 1, 2)
+        k = w.shape[2]
+        if pad == "same":
+            pt, pb, _ = tf_same(xt.shape[2], k, stride)
+            pl, pr, _ = tf_same(xt.shape[3], k, stride)
+        else:
+            pt = pb = pl = pr = pad
+        y = F.conv2d(F.pad(xt, (pl, pr, pt, pb)), w, None if bias is None else torch.as_tensor(bias, dtype=torch.float64), stride=stride)
+        outs.append(y.permute(0, 2, 3, 1))
+    return outs
+
+
+def rel_err(got, want):
+    want = np.asarray(want, np.float64)
+    return float(np.abs(np.asarray(got, np.float64) - want).max() / max(np.abs(want).max(), 1e-30))
+
+
+CASES = [
+    # name, B, shapes, cin, cout, k, stride, pad, ld_y
+    ("head3x3_multilevel", 2, [(12, 16), (6, 8), (3, 4)], 256, 512, 3, 1, "same", None),
+    ("head_out_cout117", 2, [(12, 16), (6, 8), (3, 4)], 256, 117, 3, 1, "same", 128),
+    ("mask_out_cout13", 2, [(12, 16)], 256, 13, 3, 1, "same", 16),
+    ("lat1x1", 2, [(7, 9)], 512, 256, 1, 1, "same", None),
+    ("down3x3s2_even", 2, [(12, 16)], 256, 256, 3, 2, "same", None),
+    ("down3x3s2_odd", 1, [(17, 23)], 256, 256, 3, 2, "same", None),
+    ("bneck1x1s2", 2, [(12, 16)], 256, 128, 1, 2, 0, None),
+    ("bneck3x3_zp1_c64", 2, [(9, 11)], 64, 64, 3, 1, 1, None),
+    ("bneck1x1_c64_c256", 3, [(10, 6)], 64, 256, 1, 1, 0, None),
+    ("ragged_rows", 1, [(5, 7)], 128, 192, 3, 1, "same", None),
+]
+
+
+def _setup(case, seed=0):
+    name, B, shapes, cin, cout, k, stride, pad, ld_y = case
+    rng = np.random.default_rng(seed)
+    xs = [torch.as_tensor(rng.standard_normal((B, h, w, cin)), dtype=torch.float64) for h, w in shapes]
+    w = rng.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)
+    bias = rng.standard_normal((cout,))
+    return name, B, shapes, cin, cout, k, stride, pad, ld_y, xs, w, bias
+
+
+def _device_weight(w, cout):
+    from pyrapose_amd.engine import _ru
+    k2 = w.reshape(-1, cout)
+    ld_w = _ru(cout, 16)
+    buf = np.zeros((k2.shape[0], ld_w), np.float32)
+    buf[:, :cout] = k2
+    return torch.from_numpy(buf).cuda(), ld_w
+
+
+def _cat_rows(ts, ld=None):
+    m = torch.cat([t.reshape(-1, t.shape[-1]) for t in ts], dim=0).to(torch.float32)
+    if ld is not None and ld != m.shape[1]:
+        p = torch.zeros((m.shape[0], ld), dtype=torch.float32)
+        p[:, : m.shape[1]] = m
+        m = p
+    return m.contiguous().cuda()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_fwd_bwd(ctx, case):
+    from pyrapose_amd import ops
+    name, B, shapes, cin, cout, k, stride, pad, ld_y, xs, w, bias = _setup(case)
+    ref = ref_conv(xs, w, bias, stride, pad)
+    out_shapes = [(r.shape[1], r.shape[2]) for r in ref]
+    if pad == "same":
+        pt, pl = tf_same(shapes[0][0], k, stride)[0], tf_same(shapes[0][1], k, stride)[0]
+    else:
+        pt = pl = pad
+    ld_y = ld_y or ((cout + 15) // 16 * 16)
+    wd, ld_w = _device_weight(w, cout)
+    x = _cat_rows(xs)
+    d = ops.make_conv_desc(B, shapes, out_shapes, cin, cout, k, stride, pt, pl, cin, ld_y, ld_w)
+    rows_out = sum(B * h * ww for h, ww in out_shapes)
+    # ---- forward: bias + residual + relu
+    rng = np.random.default_rng(1)
+    res = [torch.as_tensor(rng.standard_normal(tuple(r.shape)), dtype=torch.float64) for r in ref]
+    y = torch.full((rows_out, ld_y), float("nan"), dtype=torch.float32, device="cuda")
+    bd = torch.zeros((ld_w,), dtype=torch.float32)
+    bd[:cout] = torch.as_tensor(bias, dtype=torch.float32)
+    ops.conv_fwd(ctx, d, x, wd, bd.cuda(), _cat_rows(res, ld_y), True, y)
+    want = torch.cat([torch.relu(r + q).reshape(-1, cout) for r, q in zip(ref, res)], dim=0).numpy()
+    got = y.cpu().numpy()[:, :cout]
+    assert np.isfinite(got).all()
+    assert rel_err(got, want) < RTOL
+    # plain conv, no epilogue
+    y2 = torch.zeros_like(y)
+    ops.conv_fwd(ctx, d, x, wd, None, None, False, y2)
+    want2 = torch.cat([(r - torch.as_tensor(bias)).reshape(-1, cout) for r in ref], dim=0).numpy()
+    assert rel_err(y2.cpu().numpy()[:, :cout], want2) < RTOL
+
+    if cin % 64 != 0:
+        return
+    # ---- backward: reference by autograd in float64
+    xg = [t.clone().requires_grad_(True) for t in xs]
+    wt = torch.as_tensor(w, dtype=torch.float64).requires_grad_(True)
+    outs = []
+    for t in xg:
+        xt = t.permute(0, 3, 1, 2)
+        if pad == "same":
+            a, b_, _ = tf_same(xt.shape[2], k, stride)
+            c_, e_, _ = tf_same(xt.shape[3], k, stride)
+        else:
+            a = b_ = c_ = e_ = pad
+        outs.append(F.conv2d(F.pad(xt, (c_, e_, a, b_)), wt.permute(3, 2, 0, 1), None, stride=stride).permute(0, 2, 3, 1))
+    gys = [torch.as_tensor(rng.standard_normal(tuple(o.shape)), dtype=torch.float64) for o in outs]
+    loss = sum((o * g).sum() for o, g in zip(outs, gys))
+    grads = torch.autograd.grad(loss, xg + [wt])
+    gx_ref, gw_ref = grads[:-1], grads[-1]
+    gy = _cat_rows(gys, ld_y)
+    # bwd-data with addend and relu mask
+    addend = [torch.as_tensor(rng.standard_normal(tuple(t.shape)), dtype=torch.float64) for t in xs]
+    rsrc = [torch.as_tensor(rng.standard_normal(tuple(t.shape)), dtype=torch.float64) for t in xs]
+    dx = torch.full((x.shape[0], cin), float("nan"), dtype=torch.float32, device="cuda")
+    ops.conv_bwd_data(ctx, d, gy, wd, _cat_rows(addend), _cat_rows(rsrc), dx)
+    want = torch.cat([((g + a) * (r > 0)).reshape(-1, cin) for g, a, r in zip(gx_ref, addend, rsrc)], dim=0).numpy()
+    assert rel_err(dx.cpu().numpy(), want) < RTOL
+    dx2 = torch.zeros_like(dx)
+    ops.conv_bwd_data(ctx, d, gy, wd, None, None, dx2)
+    want = torch.cat([g.reshape(-1, cin) for g in gx_ref], dim=0).numpy()
+    assert rel_err(dx2.cpu().numpy(), want) < RTOL
+    # bwd-weight (+ bias gradient)
+    dw = torch.zeros((k * k * cin, ld_w), dtype=torch.float32, device="cuda")
+    db = torch.zeros((ld_w,), dtype=torch.float32, device="cuda")
+    ops.conv_bwd_weight(ctx, d, x, gy, dw, db)
+    assert rel_err(dw.cpu().numpy()[:, :cout], gw_ref.reshape(-1, cout).numpy()) < 5e-5
+    assert np.all(dw.cpu().numpy()[:, cout:] == 0)
+    db_ref = sum(g.reshape(-1, cout).sum(0) for g in gys).numpy()
+    assert rel_err(db.cpu().numpy()[:cout], db_ref) < 5e-5
+
+
+def test_stem_7x7_rgb(ctx):
+    """conv1: ZeroPadding2D(3) + 7x7/2 on the packed RGB(+0) input (cin == 4 path)."""
+    from pyrapose_amd import ops
+    rng = np.random.default_rng(3)
+    B, H, W = 2, 38, 50
+    x = torch.as_tensor(rng.standard_normal((B, H, W, 3)), dtype=torch.float64)
+    w = rng.standard_normal((7, 7, 3, 64)) / 12.0
+    ref = ref_conv([x], w, None, 2, 3)[0]
+    oh, ow = ref.shape[1], ref.shape[2]
+    w4 = np.concatenate([w, np.zeros((7, 7, 1, 64))], axis=2).reshape(-1, 64)
+    buf = np.zeros(((w4.shape[0] + 15) // 16 * 16, 64), np.float32)
+    buf[: w4.shape[0]] = w4
+    x3 = x.to(torch.float32).contiguous().cuda()
+    x4 = torch.empty((B * H * W, 4), dtype=torch.float32, device="cuda")
+    ops.pack_rgb_to_4(ctx, x3, x4)
+    d = ops.make_conv_desc(B, [(H, W)], [(oh, ow)], 4, 64, 7, 2, 3, 3, 4, 64, 64)
+    y = torch.empty((B * oh * ow, 64), dtype=torch.float32, device="cuda")
+    ops.conv_fwd(ctx, d, x4, torch.from_numpy(buf).cuda(), None, None, False, y)
+    assert rel_err(y.cpu().numpy(), ref.reshape(-1, 64).numpy()) < RTOL
+
+
+def test_bad_arguments_raise(ctx):
+    from pyrapose_amd import ops
+    d = ops.make_conv_desc(1, [(4, 4)], [(4, 4)], 24, 32, 3, 1, 1, 1, 24, 32, 32)   # cin not a multiple of 16
+    t = torch.zeros((16, 32), dtype=torch.float32, device="cuda")
+    with pytest.raises(ValueError):
+        ops.conv_fwd(ctx, d, t, t, None, None, False, t)
+
+
+def test_pointwise_ops(ctx):
+    from pyrapose_amd import ops
+    rng = np.random.default_rng(5)
+    B, C = 2, 64
+    # maxpool 3x3/2 'same' on even and odd extents
+    for (h, w) in ((12, 16), (13, 15)):
+        x = torch.as_tensor(rng.standard_normal((B, h, w, C)), dtype=torch.float32)
+        oh, ow = (h + 1) // 2, (w + 1) // 2
+        pt, pb, _ = tf_same(h, 3, 2)
+        pl, pr, _ = tf_same(w, 3, 2)
+        ref = F.max_pool2d(F.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb), value=float("-inf")), 3, 2).permute(0, 2, 3, 1)
+        y = torch.empty((B * oh * ow, C), dtype=torch.float32, device="cuda")
+        ops.maxpool3x3s2(ctx, B, h, w, C, x.cuda(), oh, ow, y)
+        assert torch.equal(y.cpu().view(B, oh, ow, C), ref)
+    # nearest upsample + add, x2 and the non-integer 17x23 -> 34x45 case (TF half-pixel rule)
+    from oracle import model_torch as MT
+    for (sh, sw, th, tw) in ((3, 4, 6, 8), (17, 23, 34, 45)):
+        src = torch.as_tensor(rng.standard_normal((B, sh, sw, C)), dtype=torch.float32)
+        oth = torch.as_tensor(rng.standard_normal((B, th, tw, C)), dtype=torch.float32)
+        up = MT.upsample_like(src.permute(0, 3, 1, 2), oth.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+        out = torch.empty((B * th * tw, C), dtype=torch.float32, device="cuda")
+        ops.upsample_add_fwd(ctx, B, sh, sw, th, tw, C, src.cuda(), oth.cuda(), out)
+        assert torch.equal(out.cpu().view(B, th, tw, C), up + oth)
+        # backward = adjoint of the gather
+        g = torch.as_tensor(rng.standard_normal((B, th, tw, C)), dtype=torch.float64)
+        s64 = src.double().requires_grad_(True)
+        (MT.upsample_like(s64.permute(0, 3, 1, 2), oth.permute(0, 3, 1, 2)).permute(0, 2, 3, 1) * g).sum().backward()
+        gs = torch.empty((B * sh * sw, C), dtype=torch.float32, device="cuda")
+        ops.upsample_add_bwd(ctx, B, sh, sw, th, tw, C, g.float().cuda(), None, gs)
+        assert rel_err(gs.cpu().numpy(), s64.grad.reshape(-1, C).numpy()) < 1e-6
+    a = torch.as_tensor(rng.standard_normal((1000, 8)), dtype=torch.float32)
+    out = torch.empty_like(a).cuda()
+    ops.add_n(ctx, a.cuda(), a.cuda(), a.cuda(), out)
+    assert torch.equal(out.cpu(), (a + a) + a)

@@ -1,0 +1,218 @@
+"""GPU: whole-graph parity of the HIP engine against the CPU oracle (oracle/model_torch.py, float64).
+Bar (north star): head outputs within 1e-3 relative; measured error is ~1e-5 (exact-f32 MFMA)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+
+
+def rel(got, want):
+    got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
+    return float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from pyrapose_amd.runtime import default_context
+    return default_context()
+
+
+def synth_input(rng, B, H, W):
+    """uint8 U[0,255] minus caffe BGR means (utils/image.py:58-60)."""
+    img = rng.integers(0, 256, size=(B, H, W, 3)).astype(np.float32)
+    return img - np.array([103.939, 116.779, 123.68], np.float32)
+
+
+def random_targets(rng, B, N, M, C, pos_frac=0.02, ign_frac=0.05):
+    def states(n):
+        u = rng.uniform(size=(B, n))
+        return np.where(u < pos_frac, 1.0, np.where(u < pos_frac + ign_frac, -1.0, 0.0)).astype(np.float32)
+    y_box = rng.standard_normal((B, N, 17)).astype(np.float32)
+    y_box[:, :, 16] = states(N)
+    y_cls = np.zeros((B, N, C + 1), np.float32)
+    st = states(N); y_cls[:, :, C] = st
+    lab = rng.integers(0, C, size=(B, N))
+    bi, ni = np.nonzero(st == 1)
+    y_cls[bi, ni, lab[bi, ni]] = 1.0
+    y_mask = np.zeros((B, M, C + 1), np.float32)
+    st = states(M); st[st == -1] = 0; y_mask[:, :, C] = st
+    lab = rng.integers(0, C, size=(B, M))
+    bi, ni = np.nonzero(st == 1)
+    y_mask[bi, ni, lab[bi, ni]] = 1.0
+    return y_box, y_cls, y_mask
+
+
+def test_known_answers_initial_outputs(ctx):
+    """PriorProbability(0.01): with the final cls/mask kernels zeroed every score is sigmoid(-log 99) = 0.01
+    for any input (SURVEY.md §8c known-answer tests)."""
+    from pyrapose_amd import arch
+    from pyrapose_amd.engine import Engine
+    rng = np.random.default_rng(0)
+    B, H, W, C = 1, 64, 96, 13
+    Wt = arch.init_weights(C, seed=1)
+    Wt["cls_out/kernel"][:] = 0
+    Wt["mask_out/kernel"][:] = 0
+    eng = Engine(ctx, C, B, H, W, weights=Wt, train=False)
+    box, cls, mask = eng.predict_on_batch(torch.from_numpy(synth_input(rng, B, H, W)).cuda())
+    assert cls.shape == (B, eng.N, C) and mask.shape == (B, eng.M3, C) and box.shape == (B, eng.N, 16)
+    np.testing.assert_allclose(cls.cpu().numpy(), 0.01, rtol=1e-5)
+    np.testing.assert_allclose(mask.cpu().numpy(), 0.01, rtol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96, 13), (1, 97, 131, 5)])
+def test_forward_small_vs_oracle_f64(ctx, shape):
+    from oracle import anchors_np as OA
+    from oracle import model_torch as MT
+    from pyrapose_amd import arch
+    from pyrapose_amd.engine import Engine
+    B, H, W, C = shape
+    rng = np.random.default_rng(2)
+    Wt = arch.init_weights(C, seed=3)
+    x = synth_input(rng, B, H, W)
+    eng = Engine(ctx, C, B, H, W, weights=Wt, train=False)
+    box, cls, mask = eng.predict_on_batch(torch.from_numpy(x).cuda())
+    ref = MT.forward(Wt, x, C, torch.float64, return_features=True)
+    # intermediate pins
+    for name, act in (("C3", eng.C3), ("C4", eng.C4), ("C5", eng.C5)):
+        want = ref[name].permute(0, 2, 3, 1).reshape(-1, act.C).numpy()
+        assert rel(act.t.cpu().numpy(), want) < TOL, name
+    pyr_want = np.concatenate([ref[n].permute(0, 2, 3, 1).reshape(-1, 256).numpy() for n in ("P3", "P4", "P5")])
+    assert rel(eng.pyr.t.cpu().numpy(), pyr_want) < TOL
+    reg_raw = eng.out_box.cpu().numpy()
+    assert rel(reg_raw, ref["3Dbox"].numpy()) < TOL
+    assert rel(cls.cpu().numpy(), ref["cls"].numpy()) < TOL
+    assert rel(mask.cpu().numpy(), ref["mask"].numpy()) < TOL
+    # prediction model adds Anchors + RegressBoxes3D (models/retinanet.py:302-335)
+    anc = OA.anchors_for_shape_f32((H, W))
+    want_box = OA.box3d_transform_inv_f32(anc[None], reg_raw)
+    assert np.array_equal(box.cpu().numpy(), want_box)
+
+
+def test_train_step_small_vs_oracle_f64(ctx):
+    from oracle import model_torch as MT
+    from pyrapose_amd import arch
+    from pyrapose_amd.engine import Engine
+    B, H, W, C = 2, 64, 96, 13
+    rng = np.random.default_rng(4)
+    Wt = arch.init_weights(C, seed=5)
+    x = synth_input(rng, B, H, W)
+    eng = Engine(ctx, C, B, H, W, weights=Wt, train=True)
+    y_box, y_cls, y_mask = random_targets(rng, B, eng.N, eng.M3, C)
+    tg = [torch.from_numpy(a).cuda() for a in (y_box, y_cls, y_mask)]
+    eng.set_targets(*tg)
+    eng.forward(torch.from_numpy(x).cuda())
+    eng.loss_and_backward()
+    losses_ref, g_ref, _ = MT.loss_and_grads(Wt, x, y_box, y_cls, y_mask, C, torch.float64)
+    P = eng.params
+    eng.opt.grad_norm(P.w_master, P.grad, P.scales, eng.gnorm_sq, eng.loss_sums[3:4])
+    got = eng.losses()
+    for k in ("3Dbox", "cls", "mask", "l2"):
+        assert abs(got[k] - losses_ref[k]) <= 1e-4 * max(abs(losses_ref[k]), 1e-3), (k, got[k], losses_ref[k])
+    # gradients w.r.t. the master weights (frozen-BN scale folded back, L2 term added like the optimizer does)
+    g_eff = P.export(P.grad)
+    sc = P.scales.cpu().numpy()
+    # Tolerance note: the loss has kinks (ReLU, |.|, smooth-L1 knee, p-clip); a float32 evaluation flips a few
+    # of them relative to float64, so element-wise gradient parity is bounded by that, not by the kernels:
+    # the PyTorch-CPU float32 autograd of the oracle itself differs from its float64 run by up to 2.5e-2 on
+    # this very problem (measured).  Bar: every tensor within 1e-2 in relative L2 (5e-2 of its max magnitude
+    # element-wise) AND the whole gradient vector within 2e-3 in relative L2.
+    worst, num, den = 0.0, 0.0, 0.0
+    for key, gr in g_ref.items():
+        layer, kind = key.split("/")
+        s = P.specs[layer]
+        g = g_eff[key].astype(np.float64)
+        if kind == "kernel":
+            if s.bn:
+                off = P.entries[key]["scale_off"]
+                g = g * sc[off: off + s.cout][None, None, None, :]
+            if s.l2:
+                g = g + 2 * s.l2 * Wt[key]
+        e = rel(g, gr.numpy())
+        worst = max(worst, e)
+        n_, d_ = float(((g - gr.numpy()) ** 2).sum()), float((gr.numpy() ** 2).sum())
+        num += n_; den += d_
+        assert e < 5e-2 and np.sqrt(n_ / max(d_, 1e-300)) < 1e-2, (key, e, np.sqrt(n_ / max(d_, 1e-300)))
+    assert np.sqrt(num / den) < 2e-3, np.sqrt(num / den)
+    # global norm
+    norm_ref = np.sqrt(sum(float((g.double() ** 2).sum()) for g in g_ref.values()))
+    assert abs(np.sqrt(float(eng.gnorm_sq.cpu())) - norm_ref) <= 1e-4 * norm_ref
+    # frozen tensors received no gradient
+    for key in g_eff:
+        if MT.frozen_layer(key.split("/")[0]):
+            assert not np.any(g_eff[key])
+    print("worst relative gradient error", worst, "relative L2", np.sqrt(num / den))
+
+
+def test_adam_clipnorm_kernel_vs_oracle(ctx):
+    """Multi-tensor Adam + global-norm clip on synthetic tensors, three steps, both clip branches."""
+    from pyrapose_amd import ops
+    from pyrapose_amd._lib import ParamDesc
+    rng = np.random.default_rng(9)
+    shapes = [(37, 16), (5, 48), (1, 32)]
+    descs, off = [], 0
+    for i, (r, ld) in enumerate(shapes):
+        d = ParamDesc()
+        d.offset, d.count, d.ld, d.trainable, d.scale_off, d.l2 = off, r * ld, ld, int(i != 2), (0 if i == 0 else -1), (0.01 if i == 1 else 0.0)
+        descs.append(d)
+        off += (r * ld + 63) // 64 * 64
+    total = off
+    scales = rng.uniform(0.5, 1.5, 16).astype(np.float32)
+    w0 = rng.standard_normal(total).astype(np.float32)
+    for clipnorm in (1e-3, 1e3):
+        w = torch.from_numpy(w0.copy()).cuda(); weff = torch.zeros_like(w)
+        m = torch.zeros_like(w); v = torch.zeros_like(w); gn = torch.zeros(1, device="cuda")
+        opt = ops.Optimizer(ctx, descs, total)
+        wr, mr, vr = w0.astype(np.float64), np.zeros(total), np.zeros(total)
+        for step in (1, 2, 3):
+            g = (rng.standard_normal(total) * 0.1).astype(np.float32)
+            opt.grad_norm(w, torch.from_numpy(g).cuda(), torch.from_numpy(scales).cuda(), gn, None)
+            opt.adam_step(w, weff, torch.from_numpy(g).cuda(), torch.from_numpy(scales).cuda(), m, v, gn, 1e-3, 0.9, 0.999, 1e-7, clipnorm, step)
+            ge = np.zeros(total)
+            for i, d in enumerate(descs):
+                if not d.trainable:
+                    continue
+                sl = slice(d.offset, d.offset + d.count)
+                gg = g[sl].astype(np.float64)
+                if d.scale_off >= 0:
+                    gg = gg * np.tile(scales.astype(np.float64), d.count // d.ld)
+                gg = gg + 2 * d.l2 * wr[sl]
+                ge[sl] = gg
+            norm = np.sqrt((ge ** 2).sum())
+            assert abs(np.sqrt(float(gn.cpu())) - norm) < 1e-5 * norm
+            ge = ge * (clipnorm / norm if norm >= clipnorm else 1.0)
+            lr_t = 1e-3 * np.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+            for d in descs:
+                if not d.trainable:
+                    continue
+                sl = slice(d.offset, d.offset + d.count)
+                mr[sl] = 0.9 * mr[sl] + 0.1 * ge[sl]
+                vr[sl] = 0.999 * vr[sl] + 0.001 * ge[sl] ** 2
+                wr[sl] = wr[sl] - lr_t * mr[sl] / (np.sqrt(vr[sl]) + 1e-7)
+        for d in descs:
+            sl = slice(d.offset, d.offset + d.count)
+            np.testing.assert_allclose(w.cpu().numpy()[sl], wr[sl], rtol=2e-5, atol=2e-6)
+            want_eff = wr[sl] * (np.tile(scales.astype(np.float64), d.count // d.ld) if d.scale_off >= 0 else 1.0)
+            np.testing.assert_allclose(weff.cpu().numpy()[sl], want_eff, rtol=2e-5, atol=2e-6)
+        opt.close()
+
+
+def test_forward_full_size_vs_oracle(ctx):
+    """BASELINE configs[0]: single 640x480 image, ResNet-50 PFPN inference, C=13."""
+    from oracle import model_torch as MT
+    from pyrapose_amd import arch
+    from pyrapose_amd.engine import Engine
+    B, H, W, C = 1, 480, 640, 13
+    rng = np.random.default_rng(0)
+    Wt = arch.init_weights(C, seed=0)
+    x = synth_input(rng, B, H, W)
+    eng = Engine(ctx, C, B, H, W, weights=Wt, train=False)
+    box, cls, mask = eng.predict_on_batch(torch.from_numpy(x).cuda())
+    assert box.shape == (1, 56700, 16) and cls.shape == (1, 56700, 13) and mask.shape == (1, 4800, 13)
+    with torch.no_grad():
+        ref = MT.forward(Wt, x, C, torch.float32)
+    assert rel(eng.out_box.cpu().numpy(), ref["3Dbox"].numpy()) < TOL
+    assert rel(cls.cpu().numpy(), ref["cls"].numpy()) < TOL
+    assert rel(mask.cpu().numpy(), ref["mask"].numpy()) < TOL
