@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--dump-ops", default=None, help="write a per-launch table (name, kind, GFLOP, avg us, TFLOP/s)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -175,6 +176,22 @@ def main():
                     "frac": fl / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                     "kernel": "conv implicit-GEMM family (igemm_kernel fwd/bwd-data + wgrad_kernel), f32 MFMA 32x32x2",
                     "dominant": dom[0], "conv_share_of_step": sec / dt, "per_kernel": kernels}
+
+    if args.dump_ops and records:
+        per = {}
+        order = []
+        for kind, name, flops, s, e in records:
+            key = (kind, name)
+            if key not in per:
+                per[key] = [flops, 0.0, 0]
+                order.append(key)
+            per[key][1] += s.elapsed_time(e) * 1e-3
+            per[key][2] += 1
+        with open(args.dump_ops, "w") as f:
+            f.write("kind,name,gflop,avg_us,tflops\n")
+            for key in order:
+                fl, sec, n = per[key]
+                f.write("%s,%s,%.3f,%.1f,%.1f\n" % (key[0], key[1], fl / 1e9, 1e6 * sec / n, fl / (sec / n) / 1e12))
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of one convolution shape through the C ABI (fwd / bwd-data / bwd-weight).
+Usage: python3 tools/conv_bench.py [--shape reg|cls|res5|res4|res2c] [--iters 20] [--mode fwd,dgrad,wgrad]
+Prints one line per mode: avg us, TFLOP/s, fraction of the 157.3 TFLOP/s f32-MFMA peak."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pyrapose_amd import ops  # noqa: E402
+
+SHAPES = {
+    # name: (B, shapes, cin, cout, k, stride, pad)
+    "reg": (8, [(60, 80), (30, 40), (15, 20)], 512, 512, 3, 1, 1),
+    "reg0": (8, [(60, 80), (30, 40), (15, 20)], 256, 512, 3, 1, 1),
+    "regout": (8, [(60, 80), (30, 40), (15, 20)], 512, 144, 3, 1, 1),
+    "cls": (8, [(60, 80), (30, 40), (15, 20)], 256, 256, 3, 1, 1),
+    "mask": (8, [(60, 80)], 256, 256, 3, 1, 1),
+    "res5": (8, [(15, 20)], 512, 512, 3, 1, 1),
+    "res5c": (8, [(15, 20)], 512, 2048, 1, 1, 0),
+    "res5a": (8, [(15, 20)], 2048, 512, 1, 1, 0),
+    "res4": (8, [(30, 40)], 256, 256, 3, 1, 1),
+    "res4c": (8, [(30, 40)], 256, 1024, 1, 1, 0),
+    "res3": (8, [(60, 80)], 128, 128, 3, 1, 1),
+    "res3c": (8, [(60, 80)], 128, 512, 1, 1, 0),
+    "res2c": (8, [(120, 160)], 64, 256, 1, 1, 0),
+    "res2b": (8, [(120, 160)], 64, 64, 3, 1, 1),
+    # occupancy probes: exactly 1024 / 512 / 256 / 2048 workgroups of 128x128 at cout 512
+    "occ4": (8, [(64, 64)], 512, 512, 3, 1, 1),
+    "occ2": (4, [(64, 64)], 512, 512, 3, 1, 1),
+    "occ1": (2, [(64, 64)], 512, 512, 3, 1, 1),
+    "occ8": (16, [(64, 64)], 512, 512, 3, 1, 1),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="reg")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--mode", default="fwd,dgrad,wgrad")
+    args = ap.parse_args()
+    ctx = ops.Context(0)
+    for name in args.shape.split(","):
+        B, shapes, cin, cout, k, stride, pad = SHAPES[name]
+        rows = sum(B * h * w for h, w in shapes)
+        ld_w = (cout + 15) // 16 * 16
+        d = ops.make_conv_desc(B, shapes, shapes, cin, cout, k, stride, pad, pad, cin, ld_w, ld_w)
+        g = torch.Generator(device="cuda").manual_seed(0)
+        x = torch.randn((rows, cin), device="cuda", generator=g)
+        w = torch.randn((k * k * cin, ld_w), device="cuda", generator=g) * 0.02
+        y = torch.empty((rows, ld_w), device="cuda")
+        dy = torch.randn((rows, ld_w), device="cuda", generator=g)
+        if ld_w != cout:
+            dy[:, cout:] = 0
+            w[:, cout:] = 0
+        dx = torch.empty((rows, cin), device="cuda")
+        dw = torch.zeros((k * k * cin, ld_w), device="cuda")
+        db = torch.zeros((ld_w,), device="cuda")
+        bias = torch.zeros((ld_w,), device="cuda")
+        flops = 2.0 * rows * k * k * cin * cout
+        fns = {"fwd": lambda: ops.conv_fwd(ctx, d, x, w, bias, None, True, y),
+               "dgrad": lambda: ops.conv_bwd_data(ctx, d, dy, w, None, x, dx),
+               "wgrad": lambda: ops.conv_bwd_weight(ctx, d, x, dy, dw, db)}
+        for mode in args.mode.split(","):
+            fn = fns[mode]
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(args.iters):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            us = s.elapsed_time(e) * 1e3 / args.iters
+            tf = flops / us / 1e6
+            print("%-7s %-6s rows=%d cin=%d cout=%d k=%d  %.1f us  %.1f TFLOP/s  %.1f%% of f32-MFMA peak" %
+                  (name, mode, rows, cin, cout, k, us, tf, 100 * tf / 157.3), flush=True)
+
+
+if __name__ == "__main__":
+    main()
