@@ -154,7 +154,7 @@ class ParamStore(object):
 
 class Engine(object):
     def __init__(self, ctx, num_classes, batch, height, width, backbone="resnet50", weights=None, train=True, seed=0,
-                 lr=1e-5, clipnorm=0.001):
+                 lr=1e-5, clipnorm=0.001, freeze_backbone=False):
         self.ctx, self.C, self.B, self.H, self.W = ctx, int(num_classes), int(batch), int(height), int(width)
         self.A = arch.NUM_ANCHORS
         self.backbone = backbone
@@ -162,6 +162,10 @@ class Engine(object):
         self.lr, self.clipnorm = lr, clipnorm
         self.beta1, self.beta2, self.eps = 0.9, 0.999, 1e-7
         self.specs = arch.all_specs(self.C, backbone)
+        if freeze_backbone:  # --freeze-backbone: utils/model.py:18-27 freeze() applied to the ResNet (bin/train.py:74)
+            for s in self.specs:
+                if s.bn:
+                    s.trainable = False
         self.params = ParamStore(self.specs, train)
         self.params.load(weights if weights is not None else arch.init_weights(self.C, seed, backbone))
         self.fwd_ops, self.graph_ops, self.bwd_ops = [], [], []

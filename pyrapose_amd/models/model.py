@@ -1,0 +1,238 @@
+"""Keras-``Model``-shaped handles over the HIP engine, so that the reference's callers keep working:
+bin/train.py:65-68,95-102,361,381-390 (load_weights / compile / summary / fit_generator),
+utils/linemod_eval.py:303 (predict_on_batch), models/__init__.py:79-80 (output_names),
+models/retinanet.py:323 (get_layer('P3').output).
+
+The Keras graph is shape-polymorphic (Input(None, None, 3)); the engine plans launches for one
+(batch, height, width), so a handle builds its engine on first use and rebuilds it (weights carried
+over) when the batch shape changes.
+"""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .. import arch, losses as losses_mod, optimizers
+from ..engine import Engine
+from ..runtime import default_context
+
+OUTPUT_NAMES = ["3Dbox", "cls", "mask"]
+
+
+class _LayerHandle(object):
+    def __init__(self, name, model):
+        self.name, self._model = name, model
+
+    @property
+    def output(self):
+        return ("tensor", self.name)
+
+    def get_weights(self):
+        W = self._model.get_weights_dict()
+        return [W[k] for k in (self.name + "/kernel", self.name + "/bias") if k in W]
+
+
+class PyraPoseModel(object):
+    """Training model: outputs ['3Dbox' (B,N,16), 'cls' (B,N,C), 'mask' (B,HW/64,C)]."""
+
+    def __init__(self, num_classes, backbone="resnet50", weights=None, seed=0, freeze_backbone=False, name="retinanet"):
+        self.name = name
+        self.num_classes = int(num_classes)
+        self.backbone_name = backbone
+        self.output_names = list(OUTPUT_NAMES)
+        self._weights = weights if weights is not None else arch.init_weights(self.num_classes, seed, backbone)
+        self._engine = None
+        self._loss = None
+        self._optimizer = None
+        self.freeze_backbone = freeze_backbone
+        self.stop_training = False
+        self.layers = [_LayerHandle(s.name, self) for s in arch.all_specs(self.num_classes, backbone)]
+
+    # ---- engine management ---------------------------------------------------------------------
+    def _get_engine(self, B, H, W, train):
+        e = self._engine
+        if e is not None and (e.B, e.H, e.W) == (B, H, W) and (e.train or not train):
+            return e
+        if e is not None:
+            self._weights = e.params.export()
+        lr = self._optimizer.lr if self._optimizer else 1e-5
+        clip = self._optimizer.clipnorm if self._optimizer else 0.001
+        self._engine = Engine(default_context(), self.num_classes, B, H, W, self.backbone_name, self._weights,
+                              train=train, lr=lr, clipnorm=clip, freeze_backbone=self.freeze_backbone)
+        if self._optimizer is not None:
+            self._engine.beta1, self._engine.beta2, self._engine.eps = self._optimizer.beta_1, self._optimizer.beta_2, self._optimizer.epsilon
+        if train and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            from ..parallel import DataParallel
+            DataParallel(self._engine)
+        return self._engine
+
+    # ---- Keras surface -----------------------------------------------------------------------------
+    def get_layer(self, name):
+        for l in self.layers:
+            if l.name == name:
+                return l
+        raise ValueError("No such layer: " + name)
+
+    def summary(self, print_fn=print):
+        n = sum(v.size for k, v in self.get_weights_dict().items() if k.endswith("kernel") or k.endswith("bias"))
+        print_fn("Model: %s (%s, %d classes) -- %d conv layers, %.2f M parameters, outputs %s" %
+                 (self.name, self.backbone_name, self.num_classes, len(self.layers), n / 1e6, self.output_names))
+
+    def compile(self, loss=None, optimizer=None, **kwargs):
+        loss = loss or {}
+        want = {"3Dbox": "orthogonal_l1", "cls": "focal", "mask": "focal"}
+        for k, kind in want.items():
+            l = loss.get(k)
+            if l is None or getattr(l, "kind", None) != kind:
+                raise ValueError("compile: output '%s' needs pyrapose_amd.losses.%s() (bin/train.py:95-102)" % (k, kind))
+        self._loss = loss
+        self._optimizer = optimizer or optimizers.Adam(lr=1e-5, clipnorm=0.001)
+        if self._engine is not None:
+            self._weights = self._engine.params.export()
+            self._engine = None
+
+    def get_weights_dict(self):
+        return self._engine.params.export() if self._engine is not None else self._weights
+
+    def load_weights(self, filepath, by_name=False, skip_mismatch=False):
+        """``.npz`` written by save_weights (keys = '<layer>/kernel' HWIO, '<layer>/bias', '<bn>/...').  Keras
+        ``.h5`` files need h5py, which this image does not have: convert them with
+        ``python -c "import h5py, numpy ..."`` on a machine that does."""
+        if str(filepath).endswith(".h5"):
+            raise ImportError("load_weights: reading Keras .h5 needs h5py (not installed); convert to .npz (INTEGRATION.md)")
+        data = np.load(filepath)
+        W = OrderedDict(self.get_weights_dict())
+        for k in data.files:
+            if k not in W:
+                if by_name:
+                    continue
+                raise ValueError("load_weights: unknown tensor %s" % k)
+            if W[k].shape != data[k].shape:
+                if skip_mismatch:
+                    continue
+                raise ValueError("load_weights: shape mismatch for %s: %s vs %s" % (k, W[k].shape, data[k].shape))
+            W[k] = data[k].astype(np.float32)
+        self._weights = W
+        if self._engine is not None:
+            self._engine.params.load(W)
+
+    def save_weights(self, filepath):
+        np.savez(filepath, **self.get_weights_dict())
+
+    save = save_weights
+
+    def predict_on_batch(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        B, H, W, _ = x.shape
+        eng = self._get_engine(B, H, W, train=False)
+        eng.forward(torch.from_numpy(x).cuda())
+        box, cls, mask = eng.export_outputs()
+        return [box.cpu().numpy(), cls.cpu().numpy(), mask.cpu().numpy()]
+
+    def train_on_batch(self, x, y):
+        """x (B,H,W,3) float32; y = [regression_3D (B,N,17), labels (B,N,C+1), mask (B,M,C+1)] (numpy or cuda tensors).
+        Returns [total, 3Dbox, cls, mask] like Keras."""
+        if self._loss is None:
+            raise RuntimeError("train_on_batch before compile()")
+        xt = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, np.float32)).cuda()
+        B, H, W, _ = xt.shape
+        eng = self._get_engine(B, H, W, train=True)
+        ys = [t if torch.is_tensor(t) else torch.from_numpy(np.ascontiguousarray(t, np.float32)).cuda() for t in y]
+        eng.train_step(xt, ys)
+        l = eng.losses()
+        return [l["total"], l["3Dbox"], l["cls"], l["mask"]]
+
+    def fit_generator(self, generator, steps_per_epoch=None, epochs=1, verbose=1, callbacks=None, workers=1,
+                      use_multiprocessing=False, max_queue_size=10, **kwargs):
+        """bin/train.py:381-390.  The generator follows the Sequence contract of preprocessing/generator.py:384-398."""
+        callbacks = callbacks or []
+        steps = int(steps_per_epoch or len(generator))
+        history = {"loss": []}
+        for cb in callbacks:
+            if hasattr(cb, "set_model"):
+                cb.set_model(self)
+            if hasattr(cb, "on_train_begin"):
+                cb.on_train_begin()
+        for epoch in range(epochs):
+            run = 0.0
+            for i in range(steps):
+                x, y = generator[i % len(generator)]
+                out = self.train_on_batch(x, y)
+                run += out[0]
+                if verbose and (i % 10 == 0 or i + 1 == steps):
+                    print("epoch %d step %d/%d - loss: %.4f - 3Dbox: %.4f - cls: %.4f - mask: %.4f" %
+                          (epoch + 1, i + 1, steps, out[0], out[1], out[2], out[3]))
+            logs = {"loss": run / max(steps, 1)}
+            history["loss"].append(logs["loss"])
+            if hasattr(generator, "on_epoch_end"):
+                generator.on_epoch_end()
+            for cb in callbacks:
+                if hasattr(cb, "on_epoch_end"):
+                    cb.on_epoch_end(epoch, logs)
+            if self.stop_training:
+                break
+        return history
+
+    # learning-rate access for ReduceLROnPlateau-style callbacks
+    @property
+    def lr(self):
+        return self._optimizer.lr if self._optimizer else None
+
+    def set_lr(self, lr):
+        self._optimizer.lr = float(lr)
+        if self._engine is not None:
+            self._engine.lr = float(lr)
+
+
+class PredictionModel(object):
+    """models/retinanet.py:302-335 retinanet_bbox: training model + Anchors + RegressBoxes3D;
+    predict_on_batch -> [boxes3D (B,N,16), classification (B,N,C), mask (B,HW/64,C)]."""
+
+    def __init__(self, model, anchor_params=None, name="retinanet-bbox"):
+        self.model, self.name, self.anchor_params = model, name, anchor_params
+        self.output_names = ["boxes3D", "cls", "mask"]
+
+    def predict_on_batch(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        B, H, W, _ = x.shape
+        eng = self.model._get_engine(B, H, W, train=False)
+        b, c, m = eng.predict_on_batch(torch.from_numpy(x).cuda())
+        return [b.cpu().numpy(), c.cpu().numpy(), m.cpu().numpy()]
+
+    def predict_on_batch_device(self, x_dev):
+        B, H, W, _ = x_dev.shape
+        return self.model._get_engine(B, H, W, train=False).predict_on_batch(x_dev)
+
+
+class ReduceLROnPlateau(object):
+    """keras.callbacks.ReduceLROnPlateau(monitor='loss', factor=0.1, patience=2, min_delta=1e-4) as configured at
+    bin/train.py:144-153 (host logic only)."""
+
+    def __init__(self, monitor="loss", factor=0.1, patience=2, verbose=1, mode="auto", min_delta=1e-4, cooldown=0, min_lr=0):
+        self.monitor, self.factor, self.patience, self.verbose = monitor, factor, patience, verbose
+        self.min_delta, self.cooldown, self.min_lr = min_delta, cooldown, min_lr
+        self.best, self.wait, self.cooldown_counter, self.model = float("inf"), 0, 0, None
+
+    def set_model(self, model):
+        self.model = model
+
+    def on_epoch_end(self, epoch, logs=None):
+        cur = (logs or {}).get(self.monitor)
+        if cur is None:
+            return
+        if self.cooldown_counter > 0:
+            self.cooldown_counter -= 1
+            self.wait = 0
+        if cur < self.best - self.min_delta:
+            self.best, self.wait = cur, 0
+        elif self.cooldown_counter <= 0:
+            self.wait += 1
+            if self.wait >= self.patience:
+                old = self.model.lr
+                if old > self.min_lr:
+                    new = max(old * self.factor, self.min_lr)
+                    self.model.set_lr(new)
+                    if self.verbose:
+                        print("Epoch %05d: ReduceLROnPlateau reducing learning rate to %s." % (epoch + 1, new))
+                    self.cooldown_counter, self.wait = self.cooldown, 0

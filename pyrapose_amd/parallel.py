@@ -50,7 +50,8 @@ def plan_buckets(entries, bwd_ops, bucket_bytes):
 class DataParallel(object):
     def __init__(self, engine, group=None, bucket_bytes=32 << 20):
         self.eng, self.group = engine, group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.active else 1
         self.buckets = plan_buckets(engine.params.entries, engine.bwd_ops, bucket_bytes)
         self.by_op = {}
         for (a, b, r) in self.buckets:
@@ -62,12 +63,12 @@ class DataParallel(object):
         engine.grad_sync = self
 
     def reduce_counts(self, counts):
-        if self.world > 1:
+        if self.active:
             dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
 
     def _launch(self, a, b):
         t = self.flat[a:b]
-        if self.world == 1:
+        if not self.active:
             return
         if self.on_gpu:
             ev = torch.cuda.Event()

@@ -1,0 +1,116 @@
+"""GPU: the reference-shaped Python surface (models.backbone(...).retinanet, compile, fit_generator,
+predict_on_batch, convert_model, save/load, loss functors) drives the HIP engine end to end."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class TinyGenerator(object):
+    """Sequence contract of preprocessing/generator.py:384-398 on synthetic data."""
+
+    def __init__(self, B, H, W, C, n_batches=2, seed=0):
+        from oracle import anchors_np as OA
+        rng = np.random.default_rng(seed)
+        self.batches = []
+        anchors = OA.anchors_for_shape((H, W))
+        for _ in range(n_batches):
+            x = rng.integers(0, 256, size=(B, H, W, 3)).astype(np.float32) - np.array([103.939, 116.779, 123.68], np.float32)
+            anns = []
+            for b in range(B):
+                mask = np.zeros((H, W), np.uint8)
+                bw, bh = rng.uniform(24, 60, 2)
+                x1, y1 = rng.uniform(0, W - bw), rng.uniform(0, H - bh)
+                mask[int(y1):int(y1 + bh), int(x1):int(x1 + bw)] = 1
+                box = rng.uniform(-40, 40, size=(1, 8, 3)).astype(np.float32)
+                anns.append({"mask": [mask], "labels": np.array([float(rng.integers(0, C))]),
+                             "bboxes": np.array([[x1, y1, x1 + bw, y1 + bh]]),
+                             "poses": np.array([[0.0, 0.0, 800.0, 1.0, 0.0, 0.0, 0.0]]), "segmentations": box.astype(np.float64),
+                             "cam_params": np.array([[572.4114, 573.57043, 325.2611, 242.04899]]), "mask_ids": np.array([1.0])})
+            reg, lab, msk = OA.anchor_targets_bbox(anchors, [(H, W)] * B, anns, C)
+            self.batches.append((x, [reg, lab, msk]))
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __getitem__(self, i):
+        return self.batches[i]
+
+    def on_epoch_end(self):
+        pass
+
+
+def test_train_and_predict_through_reference_api(tmp_path):
+    from pyrapose_amd import losses, models, optimizers
+    from pyrapose_amd.models.model import ReduceLROnPlateau
+    B, H, W, C = 2, 96, 128, 5
+    backbone = models.backbone("resnet50")
+    model = backbone.retinanet(C)
+    models.check_training_model(model)
+    prediction_model = models.convert_model(model)
+    model.compile(loss={"3Dbox": losses.orthogonal_l1(), "cls": losses.focal(), "mask": losses.focal()},
+                  optimizer=optimizers.Adam(lr=1e-4, clipnorm=0.001))
+    gen = TinyGenerator(B, H, W, C)
+    w_before = model.get_weights_dict()["reg_out/kernel"].copy()
+    hist = model.fit_generator(gen, steps_per_epoch=3, epochs=2, verbose=0, callbacks=[ReduceLROnPlateau(verbose=0)])
+    assert len(hist["loss"]) == 2 and all(np.isfinite(hist["loss"]))
+    w_after = model.get_weights_dict()["reg_out/kernel"]
+    assert np.abs(w_after - w_before).max() > 0            # the optimizer moved the trainable weights
+    frozen = model.get_weights_dict()["conv1/kernel"]
+    x = gen[0][0]
+    boxes3d, scores, mask = prediction_model.predict_on_batch(x)
+    N = sum(h * w for h, w in [(12, 16), (6, 8), (3, 4)]) * 9
+    assert boxes3d.shape == (B, N, 16) and scores.shape == (B, N, C) and mask.shape == (B, 12 * 16, C)
+    assert np.isfinite(boxes3d).all() and (scores > 0).all() and (scores < 1).all()
+    # save / load round trip reproduces the predictions bit for bit
+    path = os.path.join(str(tmp_path), "resnet50_linemod_01.npz")
+    model.save(path)
+    m2 = models.load_model(path, backbone_name="resnet50")
+    assert m2.num_classes == C
+    assert np.array_equal(m2.get_weights_dict()["conv1/kernel"], frozen)
+    b2, s2, k2 = models.convert_model(m2).predict_on_batch(x)
+    assert np.array_equal(b2, boxes3d) and np.array_equal(s2, scores) and np.array_equal(k2, mask)
+    with pytest.raises(ValueError):
+        backbone.retinanet(C).compile(loss={"3Dbox": losses.focal(), "cls": losses.focal(), "mask": losses.focal()})
+    with pytest.raises(ValueError):
+        models.backbone("resnet18")
+
+
+def test_loss_functors_vs_oracle():
+    from oracle import model_torch as MT
+    from pyrapose_amd import losses
+    rng = np.random.default_rng(1)
+    B, N, C = 2, 500, 7
+    logits = rng.standard_normal((B, N, C)).astype(np.float32) * 3
+    y = np.zeros((B, N, C + 1), np.float32)
+    st = rng.choice([-1.0, 0.0, 1.0], size=(B, N), p=[0.1, 0.8, 0.1]).astype(np.float32)
+    y[:, :, C] = st
+    bi, ni = np.nonzero(st == 1)
+    y[bi, ni, rng.integers(0, C, size=len(bi))] = 1
+    got = float(losses.focal()(torch.from_numpy(y).cuda(), torch.from_numpy(logits).cuda()).cpu())
+    want = float(MT.focal(torch.from_numpy(y).double(), torch.sigmoid(torch.from_numpy(logits).double())))
+    assert abs(got - want) < 1e-4 * abs(want)
+    yb = rng.standard_normal((B, N, 17)).astype(np.float32)
+    yb[:, :, 16] = st
+    pred = rng.standard_normal((B, N, 16)).astype(np.float32)
+    got = float(losses.orthogonal_l1()(torch.from_numpy(yb).cuda(), torch.from_numpy(pred).cuda()).cpu())
+    want = float(MT.orthogonal_l1(torch.from_numpy(yb).double(), torch.from_numpy(pred).double()))
+    assert abs(got - want) < 1e-4 * abs(want)
+
+
+def test_layers_and_backend_mirrors():
+    from oracle import anchors_np as OA
+    from pyrapose_amd import layers
+    feats = torch.zeros((2, 15, 20, 256), device="cuda")
+    a = layers.Anchors(size=128, stride=32)(feats)
+    want = OA.anchors_for_shape_f32((480, 640))[-15 * 20 * 9:]
+    assert a.shape == (2, 2700, 4) and np.array_equal(a[1].cpu().numpy(), want)
+    reg = torch.randn((2, 2700, 16), device="cuda")
+    got = layers.RegressBoxes3D()([a, reg]).cpu().numpy()
+    assert np.array_equal(got, OA.box3d_transform_inv_f32(want[None], reg.cpu().numpy()))
+    src = torch.randn((1, 17, 23, 8), device="cuda")
+    up = layers.UpsampleLike()([src, torch.zeros((1, 34, 45, 8), device="cuda")])
+    assert up.shape == (1, 34, 45, 8)

@@ -1,0 +1,123 @@
+"""CPU, world_size 2 over gloo: the data-parallel exchange plan (bucketed SUM all-reduce of the flat gradient
+buffer in backward-completion order + global positive counts) reproduces the single-process result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class FakeOp(object):
+    def __init__(self, wrange):
+        self.wrange = wrange
+
+
+def make_layout(sizes, frozen):
+    entries, off = {}, 0
+    for i, n in enumerate(sizes):
+        entries["t%d" % i] = dict(offset=off, count=n, trainable=(i not in frozen))
+        off += (n + 63) // 64 * 64
+    return entries, off
+
+
+def test_plan_buckets_covers_trainable_range_once():
+    from pyrapose_amd.parallel import plan_buckets
+    sizes = [1000, 64, 5000, 128, 70000, 256, 300000, 64, 9000]
+    entries, total = make_layout(sizes, frozen={0, 1})
+    names = list(entries)
+    # backward visits tensors in reverse layout order
+    ops = [FakeOp(None)]
+    for n in reversed(names[2:]):
+        e = entries[n]
+        ops.append(FakeOp((e["offset"], e["offset"] + e["count"])))
+        ops.append(FakeOp(None))
+    buckets = plan_buckets(entries, ops, bucket_bytes=256 * 1024)
+    assert len(buckets) >= 2
+    lo = entries["t2"]["offset"]; hi = entries["t8"]["offset"] + entries["t8"]["count"]
+    spans = sorted((a, b) for a, b, _ in buckets)
+    assert spans[0][0] == lo and spans[-1][1] == hi
+    for (a0, b0), (a1, b1) in zip(spans, spans[1:]):
+        assert b0 == a1                       # contiguous, no overlap, no gap
+    ready = [r for _, _, r in buckets]
+    assert ready == sorted(ready) and all(r >= 0 for r in ready)
+    # a bucket is launched only after the last weight-gradient op that writes into it
+    for a, b, r in buckets:
+        for i, op in enumerate(ops):
+            if op.wrange and a <= op.wrange[0] < b:
+                assert i <= r
+    # frozen tensors are never communicated
+    assert spans[0][0] >= entries["t1"]["offset"] + entries["t1"]["count"]
+
+
+def _worker(rank, world, port, sizes, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pyrapose_amd.parallel import DataParallel
+    entries, total = make_layout(sizes, frozen={0})
+    names = list(entries)
+
+    class Params(object):
+        pass
+
+    class Eng(object):
+        pass
+
+    eng = Eng()
+    eng.params = Params()
+    eng.params.entries = entries
+    eng.params.grad = torch.zeros(total, dtype=torch.float32)
+    eng.bwd_ops = []
+    for n in reversed(names[1:]):
+        e = entries[n]
+        eng.bwd_ops.append(FakeOp((e["offset"], e["offset"] + e["count"])))
+        eng.bwd_ops.append(FakeOp(None))
+    dp = DataParallel(eng, bucket_bytes=64 * 1024)
+    # "backward": rank r writes its share of the global-batch gradient
+    rng = np.random.default_rng(100 + rank)
+    counts = torch.tensor([3 + rank, 5 * (rank + 1), rank, 0], dtype=torch.int32)
+    dp.reduce_counts(counts)
+    for i, op in enumerate(eng.bwd_ops):
+        if op.wrange:
+            a, b = op.wrange
+            eng.params.grad[a:b] = torch.from_numpy(rng.standard_normal(b - a).astype(np.float32))
+        dp.after_bwd_op(i)
+    dp.finish()
+    q.put((rank, counts.numpy().copy(), eng.params.grad.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_allreduce_matches_single_process():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    sizes = [500, 3000, 64, 20000, 128, 40000]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, sizes, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, c, g = q.get(timeout=120)
+        res[r] = (c, g)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # expected: element-wise sum of what each rank produced
+    entries, total = make_layout(sizes, frozen={0})
+    want = np.zeros(total, np.float32)
+    for rank in range(2):
+        rng = np.random.default_rng(100 + rank)
+        part = np.zeros(total, np.float32)
+        for n in reversed(list(entries)[1:]):
+            e = entries[n]
+            part[e["offset"]: e["offset"] + e["count"]] = rng.standard_normal(e["count"]).astype(np.float32)
+        want += part
+    for rank in range(2):
+        c, g = res[rank]
+        assert np.array_equal(c, np.array([7, 15, 1, 0], np.int32))
+        np.testing.assert_allclose(g, want, rtol=1e-6, atol=1e-6)
+    assert np.array_equal(res[0][1], res[1][1])   # both ranks hold the identical reduced buffer
