@@ -172,8 +172,15 @@ def main():
         # the three kernels share one MFMA core; the headline fraction covers the whole conv family
         fl = sum(v[0] for v in agg.values())
         sec = sum(v[1] for v in agg.values())
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath) and (C, H, W, B) == (13, 480, 640, 8):
+            with open(tpath) as f:
+                tj = json.load(f)
+            traffic = {"hbm_bytes_per_launch": tj["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"],
+                       "launch": tj["kernel"], "source": tj["source"]}
         roofline = {"bound": "mfma", "achieved": fl / sec / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": fl / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "frac": fl / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                     "kernel": "conv implicit-GEMM family (igemm_kernel fwd/bwd-data + wgrad_kernel), f32 MFMA 32x32x2",
                     "dominant": dom[0], "conv_share_of_step": sec / dt, "per_kernel": kernels}
 

@@ -73,8 +73,11 @@ def upsample_like(src, target):
 
 
 def resnet50(x, W, dtype, blocks=None):
-    """keras_resnet.models.ResNet50(include_top=False, freeze_bn=True) -> [C2, C3, C4, C5]."""
+    """keras_resnet.models.ResNet50(include_top=False, freeze_bn=True) -> [C2, C3, C4, C5].
+    blocks = [3, 4, 23, 3] gives the ResNet-101 variant (keras_resnet numerical_names [F, T, T, F]: blocks of
+    stages 3 and 4 are named 'a', 'b1', 'b2', ...)."""
     blocks = blocks or RESNET50_BLOCKS
+    numerical = [False, True, True, False] if list(blocks) != RESNET50_BLOCKS else [False] * 4
     P = lambda n: _t(W[n + "/kernel"], dtype)
     y = conv2d(x, P("conv1"), None, 2, 3)                      # ZeroPadding2D(3) + 7x7/2 valid, no bias
     y = F.relu(frozen_bn(y, W, "bn_conv1", dtype))
@@ -85,7 +88,7 @@ def resnet50(x, W, dtype, blocks=None):
     for stage, n_blocks in enumerate(blocks):
         for block in range(n_blocks):
             sc = str(stage + 2)
-            bc = chr(ord("a") + block)
+            bc = ("b%d" % block) if (block > 0 and numerical[stage]) else chr(ord("a") + block)
             stride = 1 if (block != 0 or stage == 0) else 2  # Caffe style: stride on the first 1x1
             nm = lambda br: ("res%s%s_branch%s" % (sc, bc, br), "bn%s%s_branch%s" % (sc, bc, br))
             c, b = nm("2a")

@@ -255,3 +255,78 @@ def test_data_parallel_path_single_rank_nccl(ctx):
     finally:
         eng.grad_sync = None
         dist.destroy_process_group()
+
+
+def test_forward_tless_720x540_c30_vs_oracle(ctx):
+    """BASELINE configs[4] geometry: 720x540, 30 classes -> levels 68x90 / 34x45 / 17x23 (odd extents: TF 'same'
+    pads (1,1) on the stride-2 convs, nearest upsample 23 -> 45 is not x2), N = 72369 anchors."""
+    from oracle import model_torch as MT
+    from pyrapose_amd import arch
+    from pyrapose_amd.engine import Engine
+    B, H, W, C = 1, 540, 720, 30
+    rng = np.random.default_rng(10)
+    Wt = arch.init_weights(C, seed=11)
+    x = synth_input(rng, B, H, W)
+    eng = Engine(ctx, C, B, H, W, weights=Wt, train=False)
+    assert eng.N == 72369 and eng.M3 == 6120
+    box, cls, mask = eng.predict_on_batch(torch.from_numpy(x).cuda())
+    with torch.no_grad():
+        ref = MT.forward(Wt, x, C, torch.float32)
+    assert rel(eng.out_box.cpu().numpy(), ref["3Dbox"].numpy()) < TOL
+    assert rel(cls.cpu().numpy(), ref["cls"].numpy()) < TOL
+    assert rel(mask.cpu().numpy(), ref["mask"].numpy()) < TOL
+
+
+def test_resnet101_variant_and_ycbv_classes(ctx):
+    """Build-side extension: ResNet-101 [3,4,23,3] backbone, 21 classes (YCB-V), train step."""
+    from oracle import model_torch as MT
+    from pyrapose_amd import arch
+    from pyrapose_amd.engine import Engine
+    B, H, W, C = 1, 97, 131, 21
+    rng = np.random.default_rng(12)
+    Wt = arch.init_weights(C, seed=13, backbone="resnet101")
+    x = synth_input(rng, B, H, W)
+    eng = Engine(ctx, C, B, H, W, backbone="resnet101", weights=Wt, train=True)
+    y_box, y_cls, y_mask = random_targets(rng, B, eng.N, eng.M3, C, pos_frac=0.05)
+    eng.train_step(torch.from_numpy(x).cuda(), [torch.from_numpy(a).cuda() for a in (y_box, y_cls, y_mask)])
+    got = eng.losses()
+    ref, _, out = MT.loss_and_grads(Wt, x, y_box, y_cls, y_mask, C, torch.float64, blocks=[3, 4, 23, 3])
+    for k in ("3Dbox", "cls", "mask"):
+        assert abs(got[k] - ref[k]) <= 1e-4 * max(abs(ref[k]), 1e-3), (k, got[k], ref[k])
+    box, cls, mask = eng.export_outputs()
+    # the optimizer has already stepped, so compare only shapes here; forward parity of the R-101 graph:
+    eng2 = Engine(ctx, C, B, H, W, backbone="resnet101", weights=Wt, train=False)
+    eng2.forward(torch.from_numpy(x).cuda())
+    b2, c2, m2 = eng2.export_outputs()
+    assert rel(b2.cpu().numpy(), out["3Dbox"].detach().numpy()) < TOL
+    assert rel(c2.cpu().numpy(), out["cls"].detach().numpy()) < TOL
+
+
+def test_inference_batch_decode_and_compaction(ctx):
+    """BASELINE configs[2] shape (Occlusion-LineMOD, 8 classes): forward + Anchors + RegressBoxes3D + score
+    threshold compaction, against the oracle on a 4-image batch (the bench-scale batch is 32)."""
+    from oracle import anchors_np as OA
+    from oracle import model_torch as MT
+    from pyrapose_amd import arch, ops
+    from pyrapose_amd.engine import Engine
+    B, H, W, C = 4, 128, 160, 8
+    rng = np.random.default_rng(14)
+    Wt = arch.init_weights(C, seed=15)
+    Wt["cls_out/bias"][:] = -0.2   # ~45 % of the scores above 0.5 -> exercises the compaction
+    Wt["cls_out/kernel"] *= 30
+    x = synth_input(rng, B, H, W)
+    eng = Engine(ctx, C, B, H, W, weights=Wt, train=False)
+    box, cls, mask = eng.predict_on_batch(torch.from_numpy(x).cuda())
+    idx, cnt = ops.score_threshold_compact(ctx, cls, 0.5)
+    with torch.no_grad():
+        ref = MT.forward(Wt, x, C, torch.float64)
+    assert rel(cls.cpu().numpy(), ref["cls"].numpy()) < TOL
+    got_scores = cls.cpu().numpy()
+    idx, cnt = idx.cpu().numpy(), cnt.cpu().numpy()
+    assert cnt.sum() > 100
+    for b in range(B):
+        want = OA.score_threshold_indices(got_scores[b], 0.5)
+        for c in range(C):
+            assert np.array_equal(idx[b, c, : cnt[b, c]], want[c])
+    anc = OA.anchors_for_shape_f32((H, W))
+    assert np.array_equal(box.cpu().numpy(), OA.box3d_transform_inv_f32(anc[None], eng.out_box.cpu().numpy()))
