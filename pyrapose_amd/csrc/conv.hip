@@ -122,7 +122,7 @@ __device__ __forceinline__ bool tap_offset(const IgemmParams& p, const RowPos& r
 // BT: the B (weight) tile is read transposed -- rows = output channel, 16 contiguous reduction
 // channels (bwd-data);  SMALLC: packed-RGB stem, Cred == 4, one tap per float4.
 template <int TM, int TN, bool BT, bool SMALLC>
-__global__ __launch_bounds__(256, 4) void igemm_kernel(const IgemmParams p, const float* __restrict__ g_src,
+__global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : 4) void igemm_kernel(const IgemmParams p, const float* __restrict__ g_src,
                                                        const float* __restrict__ g_wgt, const float* __restrict__ g_bias,
                                                        const float* __restrict__ g_addend, const float* __restrict__ g_mask,
                                                        float* __restrict__ g_out) {
@@ -313,69 +313,76 @@ __global__ __launch_bounds__(256, 4) void igemm_kernel(const IgemmParams p, cons
   // row-contiguous access (32 lanes = one 512 B row segment), independent of the MFMA register layout.
   // Pass hm handles the 32*TM rows owned by the waves with wm == hm.  Columns are processed in float4
   // groups up to Nout rounded up to 4 (the weight padding columns are zero, so zeros land there).
-  constexpr int ROWS = 32 * TM;          // rows per pass
+  constexpr int SUB = (TM * BN > 256) ? 2 : TM;  // accumulator sub-rows staged per pass (LDS holds 32*SUB rows)
+  constexpr int ROWS = 32 * SUB;         // rows per pass
   constexpr int C4 = BN / 4;             // float4 groups per row
   constexpr int RPI = 256 / C4;          // rows covered by one sweep of the 256 threads
   constexpr int SWEEPS = ROWS / RPI;
+  static_assert(ROWS * BN <= 2 * BK * (BM + BN), "epilogue staging does not fit the LDS buffers");
   float* stage = smem;                   // [ROWS][BN]
   const int e_c4 = tid % C4, e_r = tid / C4;
   const int co = n0 + 4 * e_c4;
   const bool col_ok = co < ((p.Nout + 3) & ~3);
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (g_bias && col_ok) bias4 = *reinterpret_cast<const float4*>(g_bias + co);
-  typedef typename VecT<TN>::type OV;
+  const int m_last = p.M - 1;
 #pragma unroll
   for (int hm = 0; hm < 2; ++hm) {
-    __syncthreads();  // staging area free (K loop reads / previous pass reads done)
-    if (wm == hm) {
 #pragma unroll
-      for (int a = 0; a < TM; ++a)
+    for (int a0 = 0; a0 < TM; a0 += SUB) {
+      __syncthreads();  // staging area free (K loop reads / previous pass reads done)
+      if (wm == hm) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = ((r & 3) + 8 * (r >> 2) + 4 * h) * TM + a;
-          float* dst = stage + row * BN + b_col;
-          if (TN == 1) dst[0] = acc[a][0][r];
-          if (TN == 2) *reinterpret_cast<float2*>(dst) = make_float2(acc[a][0][r], acc[a][TN > 1 ? 1 : 0][r]);
-          if (TN == 4)
-            *reinterpret_cast<float4*>(dst) = make_float4(acc[a][0][r], acc[a][TN > 1 ? 1 : 0][r], acc[a][TN > 2 ? 2 : 0][r], acc[a][TN > 3 ? 3 : 0][r]);
-        }
-    }
-    __syncthreads();
-    if (col_ok) {
-      // straight-line load groups: rows are clamped (never predicated) and the has-addend / has-mask cases are
-      // wave-uniform branches, so the compiler can keep a whole group of loads in flight behind ONE wait
-      constexpr int G = SWEEPS < 4 ? SWEEPS : 4;
-      const int m_last = p.M - 1;
-      auto sweep = [&](auto has_add, auto has_mask) {
+        for (int as = 0; as < SUB; ++as)
 #pragma unroll
-        for (int s0 = 0; s0 < SWEEPS; s0 += G) {
-          float4 ad[G], mk[G];
-#pragma unroll
-          for (int g = 0; g < G; ++g) {
-            const int m = min(m0 + hm * ROWS + e_r + RPI * (s0 + g), m_last);
-            if (has_add) ad[g] = *reinterpret_cast<const float4*>(g_addend + (long long)m * p.ld_add + co);
-            if (has_mask) mk[g] = *reinterpret_cast<const float4*>(g_mask + (long long)m * p.ld_mask + co);
+          for (int r = 0; r < 16; ++r) {
+            const int row = ((r & 3) + 8 * (r >> 2) + 4 * h) * SUB + as;
+            float* dst = stage + row * BN + b_col;
+            const int a = a0 + as;
+            if (TN == 1) dst[0] = acc[a][0][r];
+            if (TN == 2) *reinterpret_cast<float2*>(dst) = make_float2(acc[a][0][r], acc[a][TN > 1 ? 1 : 0][r]);
+            if (TN == 4)
+              *reinterpret_cast<float4*>(dst) = make_float4(acc[a][0][r], acc[a][TN > 1 ? 1 : 0][r], acc[a][TN > 2 ? 2 : 0][r], acc[a][TN > 3 ? 3 : 0][r]);
           }
+      }
+      __syncthreads();
+      if (col_ok) {
+        // straight-line load groups: rows are clamped (never predicated) and the has-addend / has-mask cases are
+        // wave-uniform branches, so the compiler can keep a whole group of loads in flight behind ONE wait
+        constexpr int G = SWEEPS < 4 ? SWEEPS : 4;
+        // staged row sr holds tile row (sr / SUB) * TM + a0 + sr % SUB of the half owned by wm == hm
+        auto tile_row = [&](int sr) { return m0 + hm * 32 * TM + (sr / SUB) * TM + a0 + (sr % SUB); };
+        auto sweep = [&](auto has_add, auto has_mask) {
 #pragma unroll
-          for (int g = 0; g < G; ++g) {
-            const int row = e_r + RPI * (s0 + g);
-            const int m = m0 + hm * ROWS + row;
-            float4 v = *reinterpret_cast<const float4*>(stage + row * BN + 4 * e_c4);
-            v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-            if (has_add) { v.x += ad[g].x; v.y += ad[g].y; v.z += ad[g].z; v.w += ad[g].w; }
-            if (has_mask) {
-              v.x = mk[g].x > 0.f ? v.x : 0.f; v.y = mk[g].y > 0.f ? v.y : 0.f;
-              v.z = mk[g].z > 0.f ? v.z : 0.f; v.w = mk[g].w > 0.f ? v.w : 0.f;
+          for (int s0 = 0; s0 < SWEEPS; s0 += G) {
+            float4 ad[G], mk[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+              const int m = min(tile_row(e_r + RPI * (s0 + g)), m_last);
+              if (has_add) ad[g] = *reinterpret_cast<const float4*>(g_addend + (long long)m * p.ld_add + co);
+              if (has_mask) mk[g] = *reinterpret_cast<const float4*>(g_mask + (long long)m * p.ld_mask + co);
             }
-            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (m <= m_last) *reinterpret_cast<float4*>(g_out + (long long)m * p.ld_out + co) = v;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+              const int row = e_r + RPI * (s0 + g);
+              const int m = tile_row(row);
+              float4 v = *reinterpret_cast<const float4*>(stage + row * BN + 4 * e_c4);
+              v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+              if (has_add) { v.x += ad[g].x; v.y += ad[g].y; v.z += ad[g].z; v.w += ad[g].w; }
+              if (has_mask) {
+                v.x = mk[g].x > 0.f ? v.x : 0.f; v.y = mk[g].y > 0.f ? v.y : 0.f;
+                v.z = mk[g].z > 0.f ? v.z : 0.f; v.w = mk[g].w > 0.f ? v.w : 0.f;
+              }
+              if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+              if (m <= m_last) *reinterpret_cast<float4*>(g_out + (long long)m * p.ld_out + co) = v;
+            }
           }
-        }
-      };
-      if (g_addend != nullptr && g_mask != nullptr) sweep(std::true_type{}, std::true_type{});
-      else if (g_addend != nullptr) sweep(std::true_type{}, std::false_type{});
-      else if (g_mask != nullptr) sweep(std::false_type{}, std::true_type{});
-      else sweep(std::false_type{}, std::false_type{});
+        };
+        if (g_addend != nullptr && g_mask != nullptr) sweep(std::true_type{}, std::true_type{});
+        else if (g_addend != nullptr) sweep(std::true_type{}, std::false_type{});
+        else if (g_mask != nullptr) sweep(std::false_type{}, std::true_type{});
+        else sweep(std::false_type{}, std::false_type{});
+      }
     }
   }
 }
@@ -698,6 +705,8 @@ extern "C" int pp_conv2d_nhwc_fwd(pp_ctx* ctx, const pp_conv_desc* d, const floa
   if (d->cin == 4) {
     if (tn == 1) launch_igemm<2, 1, false, true>(ctx->stream, p);
     else launch_igemm<2, 2, false, true>(ctx->stream, p);
+  } else if (tm == 4) {
+    launch_igemm<4, 2, false, false>(ctx->stream, p);
   } else if (tm == 2) {
     if (tn == 1) launch_igemm<2, 1, false, false>(ctx->stream, p);
     else launch_igemm<2, 2, false, false>(ctx->stream, p);
@@ -737,7 +746,9 @@ extern "C" int pp_conv2d_nhwc_bwd_data(pp_ctx* ctx, const pp_conv_desc* d, const
   p.mul = 1; p.tsign = -1; p.off_y = d->pad_t; p.off_x = d->pad_l; p.div = d->stride;
   int tm, tn;
   pick_tile(ctx, p.M, p.Nout, &tm, &tn);
-  if (tm == 2) {
+  if (tm == 4) {
+    launch_igemm<4, 2, true, false>(ctx->stream, p);
+  } else if (tm == 2) {
     if (tn == 1) launch_igemm<2, 1, true, false>(ctx->stream, p);
     else launch_igemm<2, 2, true, false>(ctx->stream, p);
   } else {

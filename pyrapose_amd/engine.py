@@ -29,10 +29,10 @@ def tf_same_pad(n_in, k, s):
 
 class Op(object):
     """One C-ABI launch of the plan: `fn()` enqueues it on the ctx stream."""
-    __slots__ = ("fn", "kind", "name", "flops", "wrange")
+    __slots__ = ("fn", "kind", "name", "flops", "wrange", "lane")
 
-    def __init__(self, fn, kind, name="", flops=0.0, wrange=None):
-        self.fn, self.kind, self.name, self.flops, self.wrange = fn, kind, name, flops, wrange
+    def __init__(self, fn, kind, name="", flops=0.0, wrange=None, lane=0):
+        self.fn, self.kind, self.name, self.flops, self.wrange, self.lane = fn, kind, name, flops, wrange, lane
 
     def __call__(self):
         self.fn()
@@ -169,6 +169,15 @@ class Engine(object):
         self.params = ParamStore(self.specs, train)
         self.params.load(weights if weights is not None else arch.init_weights(self.C, seed, backbone))
         self.fwd_ops, self.graph_ops, self.bwd_ops = [], [], []
+        # Launch lanes: lane 0 is the ctx stream; lanes 1-2 are side streams.  Independent kernel chains (the three
+        # heads in forward; weight gradients vs the data-gradient chain in backward) are enqueued on different
+        # lanes so that the tail of one launch (last, partially filled round of workgroups) is covered by
+        # workgroups of another -- see DESIGN.md §Concurrency.  PP_LANES=1 serialises everything on lane 0.
+        import os
+        self.n_lanes = max(1, min(3, int(os.environ.get("PP_LANES", "3"))))
+        self.streams = [ctx.stream] + [torch.cuda.Stream(device=ctx.device) for _ in range(self.n_lanes - 1)]
+        self.ctxs = [ctx] + [ops.Context(ctx.device, st) for st in self.streams[1:]]
+        self._lane = 0
         self.acts = OrderedDict()
         self.step_count = 0
         self._build_forward()
@@ -220,10 +229,11 @@ class Engine(object):
         desc = ops.make_conv_desc(self.B, x.shapes, out_shapes, cin_eff, s.cout, k, st, pt, pl, x.ld, ld_y, ek["ld"])
         w = self.params.view(self.params.w_eff, spec_name + "/kernel")
         b = self.params.view(self.params.w_eff, spec_name + "/bias")
-        ctx = self.ctx
+        lane = self._lane
+        ctx = self.ctxs[lane]
         rt = residual.t if residual is not None else None
         flops = 2.0 * y.rows * k * k * s.cin * s.cout
-        self.fwd_ops.append(Op(lambda: ops.conv_fwd(ctx, desc, x.t, w, b, rt, relu, y.t), "conv_fwd", spec_name, flops))
+        self.fwd_ops.append(Op(lambda: ops.conv_fwd(ctx, desc, x.t, w, b, rt, relu, y.t), "conv_fwd", spec_name, flops, None, lane))
         self.graph_ops.append(dict(kind="conv", spec=s, x=x, y=y, residual=residual, desc=desc, w=w, flops=flops))
         return y
 
@@ -285,9 +295,23 @@ class Engine(object):
             for i in range(4):
                 y = self._conv("%s_conv%d" % (prefix, i), y, relu=True)
             return self._conv(prefix + "_out", y)
+        self.fwd_fork = len(self.fwd_ops)  # everything before this index is the serial trunk (lane 0)
+        self._lane = 0
         self.reg_out = run_head("reg", pyr)
+        self._lane = 1 % self.n_lanes
         self.cls_out = run_head("cls", pyr)
+        self._lane = 2 % self.n_lanes
         self.mask_out = run_head("mask", P3)
+        self._lane = 0
+        # interleave the three chains in enqueue order so that every lane has work from the start
+        trunk, heads = self.fwd_ops[: self.fwd_fork], self.fwd_ops[self.fwd_fork:]
+        by_lane = [[o for o in heads if o.lane == l] for l in range(self.n_lanes)]
+        mixed = []
+        for i in range(max(len(c) for c in by_lane)):
+            for c in by_lane:
+                if i < len(c):
+                    mixed.append(c[i])
+        self.fwd_ops = trunk + mixed
 
     def _upadd(self, name, src, other):
         (sh, sw), (th, tw) = src.shapes[0], other.shapes[0]
@@ -365,8 +389,10 @@ class Engine(object):
                     ek = P.entries[s.name + "/kernel"]
                     eb = P.entries[s.name + "/bias"]
                     wr = (ek["offset"], eb["offset"] + eb["count"])
-                    self.bwd_ops.append(Op(lambda d=op["desc"], xt=x.t, g=g, dw=dw, db=db: ops.conv_bwd_weight(ctx, d, xt, g, dw, db),
-                                           "conv_wgrad", s.name, op["flops"], wr))
+                    wl = 1 % self.n_lanes
+                    wctx = self.ctxs[wl]
+                    self.bwd_ops.append(Op(lambda d=op["desc"], xt=x.t, g=g, dw=dw, db=db, wctx=wctx: ops.conv_bwd_weight(wctx, d, xt, g, dw, db),
+                                           "conv_wgrad", s.name, op["flops"], wr, wl))
                 if x.needs_grad:
                     x.contribs.append(("dgrad", op, g))
                 r = op["residual"]
@@ -393,11 +419,31 @@ class Engine(object):
                     r0 += n
 
     # ------------------------------------------------------------------------------------ execution
+    def _fork(self, lanes):
+        """side lanes wait for everything enqueued on lane 0 so far"""
+        if self.n_lanes == 1:
+            return
+        ev = torch.cuda.Event()
+        ev.record(self.streams[0])
+        for l in lanes:
+            self.streams[l].wait_event(ev)
+
+    def _join(self, lanes):
+        """lane 0 waits for everything enqueued on the side lanes so far"""
+        for l in lanes:
+            ev = torch.cuda.Event()
+            ev.record(self.streams[l])
+            self.streams[0].wait_event(ev)
+
     def forward(self, x=None):
         if x is not None:
             self.x_in.copy_(x)
-        for f in self.fwd_ops:
+        side = list(range(1, self.n_lanes))
+        for i, f in enumerate(self.fwd_ops):
+            if i == self.fwd_fork:
+                self._fork(side)
             f()
+        self._join(side)
 
     def export_outputs(self):
         """Keras prediction-model outputs (models/retinanet.py:302-335): [boxes3D, cls probs, mask probs]."""
@@ -444,9 +490,12 @@ class Engine(object):
                   self.loss_sums[2:3], self.g_mask)
         sync = self.grad_sync
         for i, op in enumerate(self.bwd_ops):
+            if op.lane:
+                self._fork([op.lane])  # the weight gradient needs the gradient tensor lane 0 has just produced
             op()
             if sync is not None:
-                sync.after_bwd_op(i)
+                sync.after_bwd_op(i, self.streams[op.lane])
+        self._join(list(range(1, self.n_lanes)))
 
     def optimizer_step(self):
         P = self.params

@@ -66,22 +66,23 @@ class DataParallel(object):
         if self.active:
             dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
 
-    def _launch(self, a, b):
+    def _launch(self, a, b, stream=None):
         t = self.flat[a:b]
         if not self.active:
             return
         if self.on_gpu:
             ev = torch.cuda.Event()
-            ev.record()
+            ev.record(stream if stream is not None else torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
                 self.works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
-    def after_bwd_op(self, i):
+    def after_bwd_op(self, i, stream=None):
+        """`stream` = the stream op i was enqueued on (weight gradients run on a side lane)."""
         for (a, b) in self.by_op.get(i, ()):
-            self._launch(a, b)
+            self._launch(a, b, stream)
 
     def finish(self):
         for (a, b) in self.by_op.get(-1, ()):  # buckets no weight-gradient op maps to (defensive)

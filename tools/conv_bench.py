@@ -32,6 +32,7 @@ SHAPES = {
     "occ2": (4, [(64, 64)], 512, 512, 3, 1, 1),
     "occ1": (2, [(64, 64)], 512, 512, 3, 1, 1),
     "occ8": (16, [(64, 64)], 512, 512, 3, 1, 1),
+    "big2": (16, [(64, 64)], 512, 512, 3, 1, 1),   # 256x128 tiles: 256*4 = 1024 workgroups = 2 per CU x 2 rounds
 }
 
 
