@@ -28,7 +28,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_F32_MFMA_TFLOPS = 157.3   # dense f32 MFMA, MI355X_MICROARCH.md
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (never the 2:1-sparsity figure)
 ALGO_GFLOP_PER_IMAGE = {(13, 480, 640): 683.2}  # BASELINE.md §3 (fwd 234.2 + bwd 449.1)
 
 
@@ -72,6 +73,8 @@ def main():
     ap.add_argument("--classes", type=int, default=13)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--conv-mode", default=None, choices=["f32", "bf16x3"], help="default: env PP_CONV_MODE or bf16x3")
+    ap.add_argument("--no-alt-mode", action="store_true", help="skip the short run of the other conv mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--dump-ops", default=None, help="write a per-launch table (name, kind, GFLOP, avg us, TFLOP/s)")
@@ -98,36 +101,12 @@ def main():
     B, H, W, C = args.batch, args.height, args.width, args.classes
     ctx = default_context(local_rank)
     weights = arch.init_weights(C, seed=0)
-    eng = Engine(ctx, C, B, H, W, weights=weights, train=True)
-    if world > 1:
-        DataParallel(eng)
     x, images, anns = synth_batch(B, H, W, C, seed=1000 + rank)
     anchors = UA.anchors_for_shape_device((H, W))
     y_box, y_cls, y_mask = UA.anchor_targets_bbox_device(anchors, images, anns, C)
-    eng.set_targets(y_box, y_cls, y_mask)
-    eng.x_in.copy_(torch.from_numpy(x).cuda())
-    torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        eng.train_step()
-
-    # kernel events on the conv launches (same stream), gathered during the timed steps
-    timed_kinds = ("conv_fwd", "conv_dgrad", "conv_wgrad")
-    records = []
-    if not args.no_kernel_events:
-        def wrap(op):
-            inner = op.fn
-            st = eng.streams[op.lane]
-            def fn():
-                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s.record(st)
-                inner()
-                e.record(st)
-                records.append((op.kind, op.name, op.flops, s, e))
-            op.fn = fn
-        for op in eng.fwd_ops + eng.bwd_ops:
-            if op.kind in timed_kinds:
-                wrap(op)
+    x_dev = torch.from_numpy(x).cuda()
+    fwd_fl, bwd_fl = arch.conv_flops(C, H, W)
+    algo_gflop = ALGO_GFLOP_PER_IMAGE.get((C, H, W), (fwd_fl + bwd_fl) / 1e9)
 
     def barrier():
         torch.cuda.synchronize()
@@ -135,86 +114,128 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    base_ev = torch.cuda.Event(enable_timing=True)
-    base_ev.record(eng.streams[0])
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.train_step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    losses = eng.losses()
+    def run(mode, steps, warmup, events, dump_ops=None):
+        """Build an engine in `mode`, run warmup + timed steps, return (dt, images, losses, roofline dict)."""
+        eng = Engine(ctx, C, B, H, W, weights=weights, train=True, conv_mode=mode)
+        if world > 1:
+            DataParallel(eng)
+        eng.set_targets(y_box, y_cls, y_mask)
+        eng.x_in.copy_(x_dev)
+        torch.cuda.synchronize()
+        for _ in range(warmup):
+            eng.train_step()
+        records = []
+        if events:
+            def wrap(op):
+                inner = op.fn
+                st = eng.streams[op.lane]
+                def fn():
+                    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s.record(st)
+                    inner()
+                    e.record(st)
+                    records.append((op.kind, op.name, op.flops, s, e))
+                op.fn = fn
+            for op in eng.fwd_ops + eng.bwd_ops:
+                if op.kind in ("conv_fwd", "conv_dgrad", "conv_wgrad"):
+                    wrap(op)
+        barrier()
+        base_ev = torch.cuda.Event(enable_timing=True)
+        base_ev.record(eng.streams[0])
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.train_step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        losses = eng.losses()
+        roof = None
+        if records and rank == 0:
+            # Launches of independent chains run on different lanes (streams) and overlap, so the family rate is
+            # algorithmic flops / length of the UNION of the launch intervals (time during which >= 1 conv kernel
+            # ran); per-kernel figures use each launch's own event-bracketed interval (inflated where launches overlap).
+            agg, spans = {}, []
+            for kind, name, flops, s_ev, e_ev in records:
+                t_s, t_e = base_ev.elapsed_time(s_ev) * 1e-3, base_ev.elapsed_time(e_ev) * 1e-3
+                spans.append((t_s, t_e))
+                a = agg.setdefault(kind, [0.0, 0.0, 0])
+                a[0] += flops
+                a[1] += t_e - t_s
+                a[2] += 1
+            spans.sort()
+            union, cur_s, cur_e = 0.0, spans[0][0], spans[0][1]
+            for t_s, t_e in spans[1:]:
+                if t_s > cur_e:
+                    union += cur_e - cur_s
+                    cur_s, cur_e = t_s, t_e
+                else:
+                    cur_e = max(cur_e, t_e)
+            union += cur_e - cur_s
+            names = {"conv_fwd": "igemm fwd", "conv_dgrad": "igemm bwd-data", "conv_wgrad": "wgrad"}
+            kernels = [{"kernel": names[k], "launches": n, "avg_ms": 1e3 * sec / n, "tflops_own_interval": fl / sec / 1e12}
+                       for k, (fl, sec, n) in agg.items()]
+            fl = sum(v[0] for v in agg.values())
+            roof = {"achieved": fl / union / 1e12, "conv_share_of_step": union / dt, "lanes": eng.n_lanes,
+                    "dominant": max(agg.items(), key=lambda kv: kv[1][1])[0], "per_kernel": kernels}
+            if dump_ops:
+                per, order = {}, []
+                for kind, name, flops, s_ev, e_ev in records:
+                    key = (kind, name)
+                    if key not in per:
+                        per[key] = [flops, 0.0, 0]
+                        order.append(key)
+                    per[key][1] += s_ev.elapsed_time(e_ev) * 1e-3
+                    per[key][2] += 1
+                with open(dump_ops, "w") as f:
+                    f.write("kind,name,gflop,avg_us,tflops\n")
+                    for key in order:
+                        fl_, sec, n = per[key]
+                        f.write("%s,%s,%.3f,%.1f,%.1f\n" % (key[0], key[1], fl_ / 1e9, 1e6 * sec / n, fl_ / (sec / n) / 1e12))
+        mode_used = eng.conv_mode
+        del eng
+        torch.cuda.empty_cache()
+        return dt, steps * B * world, losses, roof, mode_used
+
+    dt, images_total, losses, roof, mode = run(args.conv_mode, args.steps, args.warmup, not args.no_kernel_events, args.dump_ops)
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
-    images_total = args.steps * B * world
     value = images_total / dt
-    fwd_fl, bwd_fl = arch.conv_flops(C, H, W)
-    algo_gflop = ALGO_GFLOP_PER_IMAGE.get((C, H, W), (fwd_fl + bwd_fl) / 1e9)
-
-    roofline, kernels = None, []
-    if records:
-        # Launches of independent chains run on different lanes (streams) and overlap, so the family rate is
-        # algorithmic flops / length of the UNION of the launch intervals (time during which >= 1 conv kernel ran);
-        # per-kernel figures use each launch's own event-bracketed duration (inflated where launches overlap).
-        agg, spans = {}, []
-        for kind, name, flops, s_ev, e_ev in records:
-            t_s, t_e = base_ev.elapsed_time(s_ev) * 1e-3, base_ev.elapsed_time(e_ev) * 1e-3
-            spans.append((t_s, t_e))
-            a = agg.setdefault(kind, [0.0, 0.0, 0])
-            a[0] += flops
-            a[1] += t_e - t_s
-            a[2] += 1
-        spans.sort()
-        union, cur_s, cur_e = 0.0, spans[0][0], spans[0][1]
-        for t_s, t_e in spans[1:]:
-            if t_s > cur_e:
-                union += cur_e - cur_s
-                cur_s, cur_e = t_s, t_e
-            else:
-                cur_e = max(cur_e, t_e)
-        union += cur_e - cur_s
-        for kind, (fl, sec, n) in agg.items():
-            kernels.append({"kernel": {"conv_fwd": "igemm_kernel<fwd>", "conv_dgrad": "igemm_kernel<bwd-data>",
-                                       "conv_wgrad": "wgrad_kernel"}[kind], "launches": n, "avg_ms": 1e3 * sec / n,
-                            "tflops_own_interval": fl / sec / 1e12})
-        dom = max(agg.items(), key=lambda kv: kv[1][1])
-        fl = sum(v[0] for v in agg.values())
+    roofline = None
+    if roof:
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tpath) and (C, H, W, B) == (13, 480, 640, 8):
             with open(tpath) as f:
                 tj = json.load(f)
-            traffic = {"hbm_bytes_per_launch": tj["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"],
-                       "launch": tj["kernel"], "source": tj["source"]}
-        roofline = {"bound": "mfma", "achieved": fl / union / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": fl / union / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                    "kernel": "conv implicit-GEMM family (igemm_kernel fwd/bwd-data + wgrad_kernel), f32 MFMA 32x32x2",
-                    "method": "sum of 2*MAC flops of every conv launch in the timed region / union of their HIP-event intervals",
-                    "dominant": dom[0], "conv_share_of_step": union / dt, "lanes": eng.n_lanes, "per_kernel": kernels}
+            traffic = tj.get(mode)
+        if mode == "bf16x3":
+            peak, kname = PEAK_BF16_MFMA_TFLOPS, "conv implicit-GEMM family (igemm3 fwd/bwd-data + wgrad3): 3 x v_mfma_f32_32x32x16_bf16 per product, f32 accumulate"
+        else:
+            peak, kname = PEAK_F32_MFMA_TFLOPS, "conv implicit-GEMM family (igemm fwd/bwd-data + wgrad): v_mfma_f32_32x32x2_f32"
+        roofline = {"bound": "mfma", "achieved": roof["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": roof["achieved"] / peak,
+                    "traffic": traffic, "kernel": kname,
+                    "method": "sum of ALGORITHMIC 2*MAC flops of every conv launch in the timed region / union of their HIP-event intervals",
+                    "mfma_flops_per_algorithmic_flop": 3 if mode == "bf16x3" else 1,
+                    "mfma_issue_frac": roof["achieved"] * (3 if mode == "bf16x3" else 1) / peak,
+                    "vs_f32_mfma_peak_157.3": roof["achieved"] / PEAK_F32_MFMA_TFLOPS,
+                    "dominant": roof["dominant"], "conv_share_of_step": roof["conv_share_of_step"], "lanes": roof["lanes"],
+                    "per_kernel": roof["per_kernel"]}
 
-    if args.dump_ops and records:
-        per = {}
-        order = []
-        for kind, name, flops, s, e in records:
-            key = (kind, name)
-            if key not in per:
-                per[key] = [flops, 0.0, 0]
-                order.append(key)
-            per[key][1] += s.elapsed_time(e) * 1e-3
-            per[key][2] += 1
-        with open(args.dump_ops, "w") as f:
-            f.write("kind,name,gflop,avg_us,tflops\n")
-            for key in order:
-                fl, sec, n = per[key]
-                f.write("%s,%s,%.3f,%.1f,%.1f\n" % (key[0], key[1], fl / 1e9, 1e6 * sec / n, fl / (sec / n) / 1e12))
+    other = None
+    if world == 1 and not args.no_alt_mode:
+        alt = "f32" if mode == "bf16x3" else "bf16x3"
+        dt2, img2, losses2, roof2, _ = run(alt, max(3, args.steps // 2), 2, True)
+        pk = PEAK_F32_MFMA_TFLOPS if alt == "f32" else PEAK_BF16_MFMA_TFLOPS
+        other = {"conv_mode": alt, "value": img2 / dt2, "unit": "images/sec", "ms_per_step": 1e3 * dt2 / max(3, args.steps // 2),
+                 "roofline_achieved_tflops": roof2["achieved"] if roof2 else None, "roofline_peak": pk,
+                 "roofline_frac": (roof2["achieved"] / pk) if roof2 else None, "losses": losses2}
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
@@ -235,13 +256,16 @@ def main():
         "metric": "images/sec 640x480 fwd+bwd (train step: fwd + losses + bwd + clipnorm-Adam)",
         "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "bf16x3" if mode == "bf16x3" else "f32", "data": "synthetic",
+        "dtype_note": ("every conv product = x_hi*w_hi + x_hi*w_lo + x_lo*w_hi on bf16 MFMA with f32 accumulation (2^-16 relative); "
+                       "activations, master weights, losses and Adam in float32; head outputs within 1e-3 of the float64 oracle "
+                       "(tests/test_gpu_model.py)") if mode == "bf16x3" else "exact f32 MFMA (v_mfma_f32_32x32x2_f32) everywhere",
         "config": {"workload": "LineMOD %d-class training, batch %d/GPU, %dx%d, ResNet-50 PFPN + heads (BASELINE configs[1])"
                                % (C, B, W, H), "global_batch": B * world, "parallelism": "dp%d" % world,
                    "algorithmic_gflop_per_image": algo_gflop},
         "step_tflops": images_total * algo_gflop / dt / 1e3,
         "losses": losses,
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": cpu, "other_mode": other,
     }
     print(json.dumps(out))
     if world > 1:

@@ -92,6 +92,28 @@ int pp_conv2d_nhwc_bwd_data(pp_ctx* ctx, const pp_conv_desc* d, const float* dy,
 int pp_conv2d_nhwc_bwd_weight(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const float* dy,
                               float* dw, float* dbias);
 
+/* ---- float32-class convolution on the bf16 matrix cores ("bf16x3") ---------------------------------------
+ * Same operators as above with every product evaluated as x_hi*w_hi + x_hi*w_lo + x_lo*w_hi on
+ * v_mfma_f32_32x32x16_bf16 (f32 accumulation; ~2^-16 relative error per product, 5.3x the f32-MFMA rate).
+ * Activations stay float32; weights are split once per optimizer step into bf16 (hi, lo) planes:
+ *   forward planes  [tap][cout][cin]              (cin % 32 == 0)
+ *   bwd-data planes [tap][cin][cout rounded to 32] (zero padded)
+ * Any of the plane pairs may be NULL in pp_conv_split_weights_bf16x3. */
+int pp_conv_split_weights_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* w, void* fwd_hi, void* fwd_lo,
+                                 void* dgrad_hi, void* dgrad_lo);
+int pp_conv2d_nhwc_fwd_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const void* w_fwd_hi,
+                              const void* w_fwd_lo, const float* bias, const float* residual, int ld_res,
+                              int relu, float* y);
+/* dy rows need ld_y >= cout rounded up to 32 with zero padding. */
+int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* dy, const void* w_dgrad_hi,
+                                   const void* w_dgrad_lo, const float* addend, int ld_add,
+                                   const float* relu_src, int ld_rs, float* dx);
+
+/* dw += x^T (*) dy with both operands split to bf16 (hi, lo) on the fly (no weight planes involved); same contract
+ * as pp_conv2d_nhwc_bwd_weight, cin % 64 == 0. */
+int pp_conv2d_nhwc_bwd_weight_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const float* dy,
+                                     float* dw, float* dbias);
+
 /* ---- pooling / resampling / pointwise --------------------------------------------------
  * keras_resnet pool1 = MaxPooling2D(3, strides 2, 'same') (called via models/resnet.py:87). */
 int pp_maxpool3x3s2_fwd(pp_ctx* ctx, int n_img, int h, int w, int c, const float* x, int oh, int ow, float* y);

@@ -1,0 +1,680 @@
+// Implicit-GEMM convolution with float32-class accuracy on the bf16 matrix cores ("bf16x3"):
+//   x = x_hi + x_lo,  w = w_hi + w_lo  (bf16 round-to-nearest of the value and of its remainder)
+//   x*w ~= x_hi*w_hi + x_hi*w_lo + x_lo*w_hi      (dropped: x_lo*w_lo and the second remainders, ~2^-16 relative)
+// Three v_mfma_f32_32x32x16_bf16 per 16-deep k-step accumulate in f32: 5.3x the per-clock rate of the exact
+// f32 MFMA (64 FLOP/clk/SIMD) at ~1.5e-5 relative error per product, which keeps the whole graph inside the
+// 1e-3 head-output bar (tests/test_gpu_model.py, mode bf16x3).  Same gather, row spaces, fusions and LDS-staged
+// epilogue as conv.hip.  Activations stay float32 in HBM: the A tile is split into hi/lo while it is staged into
+// LDS (3 VALU per element, under the MFMAs of the other waves); weights are split once per optimizer step by
+// pp_conv_split_weights_bf16x3 into k-contiguous bf16 planes (forward: [tap][cout][cin], bwd-data: [tap][cin][cout]).
+//
+// Fragment maps (cdna_hip_programming.md §3): lane l (r = l & 31, h = l >> 5) holds A[row r][k = 8h + j] and
+// B[k = 8h + j][col r], j = 0..7 -> one 16-byte LDS read per operand.  LDS image per operand plane:
+// [4 k-octets][rows][8 bf16], rows of octet o rotated by 2*o so that both the 16-byte stores of the staging
+// threads (4 threads per row) and the 512-byte fragment reads are bank-conflict free.
+#include "conv_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split8(const float4& lo4, const float4& hi4, uint4* out_hi, uint4* out_lo) {
+  const float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+  bf16x8 h, l;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 hh = (__bf16)v[j];
+    h[j] = hh;
+    l[j] = (__bf16)(v[j] - (float)hh);
+  }
+  *out_hi = *reinterpret_cast<uint4*>(&h);
+  *out_lo = *reinterpret_cast<uint4*>(&l);
+}
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3_kernel(
+    const IgemmParams p, const float* __restrict__ g_src, const uint4* __restrict__ g_whi, const uint4* __restrict__ g_wlo,
+    const float* __restrict__ g_bias, const float* __restrict__ g_addend, const float* __restrict__ g_mask,
+    float* __restrict__ g_out, int w_rows, int w_ld8) {
+  constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, NO = BK / 8;
+  constexpr int SMEM_U4 = 2 * NO * (BM + BN);
+  __shared__ __attribute__((aligned(16))) uint4 smem[SMEM_U4];
+  uint4* Ahi = smem;
+  uint4* Alo = Ahi + NO * BM;
+  uint4* Bhi = Alo + NO * BM;
+  uint4* Blo = Bhi + NO * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lb = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int tile_n = lb % p.n_tiles_n, tile_m = lb / p.n_tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // staging threads: 4 per row (one k-octet = 8 channels each), rows r0 + 64*i
+  const int oct = tid & 3, r0 = tid >> 2;
+  RowPos rows[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) rows[i] = decode_row(p, m0 + r0 + 64 * i);
+  long long a_off[TM];
+  bool a_ok[TM];
+
+  const int n_taps = p.kh * p.kw;
+  const int n_steps = n_taps * (p.Cred / BK);
+
+  float4 ra[TM][2];
+  uint4 rbh[TN], rbl[TN];
+  int tap = 0, ty = 0, tx = 0, red0 = 0;
+
+  auto set_tap = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_ok[i] = tap_offset(p, rows[i], ty, tx, &a_off[i]);
+  };
+  auto load_step = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (a_ok[i]) {
+        const float4* s4 = reinterpret_cast<const float4*>(g_src + a_off[i] + red0 + 8 * oct);
+        ra[i][0] = s4[0];
+        ra[i][1] = s4[1];
+      } else {
+        ra[i][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ra[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int n = n0 + r0 + 64 * i;
+      if (n < w_rows) {
+        const long long off = ((long long)tap * w_rows + n) * w_ld8 + (red0 >> 3) + oct;
+        rbh[i] = g_whi[off];
+        rbl[i] = g_wlo[off];
+      } else {
+        rbh[i] = make_uint4(0u, 0u, 0u, 0u);
+        rbl[i] = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  };
+  auto advance = [&]() {
+    red0 += BK;
+    if (red0 >= p.Cred) {
+      red0 = 0;
+      ++tap;
+      ++tx;
+      if (tx == p.kw) { tx = 0; ++ty; }
+      set_tap();
+    }
+  };
+  auto store_step = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      uint4 hi, lo;
+      split8(ra[i][0], ra[i][1], &hi, &lo);
+      const int slot = oct * BM + ((r0 + 64 * i + 2 * oct) & (BM - 1));
+      Ahi[slot] = hi;
+      Alo[slot] = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int slot = oct * BN + ((r0 + 64 * i + 2 * oct) & (BN - 1));
+      Bhi[slot] = rbh[i];
+      Blo[slot] = rbl[i];
+    }
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int il = lane & 31, h = lane >> 5;
+
+  set_tap();
+  load_step();
+  store_step();
+  __syncthreads();
+
+  for (int step = 0; step < n_steps; ++step) {
+    const bool more = step + 1 < n_steps;
+    if (more) {
+      advance();
+      load_step();  // in flight under the MFMAs below
+    }
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      const int o = 2 * s + h;
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const int slot = o * BM + ((wm * 32 * TM + a * 32 + il + 2 * o) & (BM - 1));
+        uint4 t = Ahi[slot];
+        ah[a] = *reinterpret_cast<bf16x8*>(&t);
+        t = Alo[slot];
+        al[a] = *reinterpret_cast<bf16x8*>(&t);
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int slot = o * BN + ((wn * 32 * TN + b * 32 + il + 2 * o) & (BN - 1));
+        uint4 t = Bhi[slot];
+        bh[b] = *reinterpret_cast<bf16x8*>(&t);
+        t = Blo[slot];
+        bl[b] = *reinterpret_cast<bf16x8*>(&t);
+      }
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    __syncthreads();  // every wave has read this step's tiles
+    if (more) {
+      store_step();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue through LDS (see conv.hip): blocked sub-tiles here, so staged row = (a - a0) * 32 + i ----
+  constexpr int SUB = (TM * BN > 256 * 1) ? 1 : TM;  // 32*SUB rows x BN floats must fit the 16*SMEM_U4-byte buffer
+  constexpr int ROWS = 32 * SUB;
+  constexpr int C4 = BN / 4;
+  constexpr int RPI = 256 / C4;
+  constexpr int SWEEPS = ROWS / RPI;
+  static_assert(ROWS * BN * 4 <= SMEM_U4 * 16, "epilogue staging does not fit");
+  float* stage = reinterpret_cast<float*>(smem);
+  const int e_c4 = tid % C4, e_r = tid / C4;
+  const int co = n0 + 4 * e_c4;
+  const bool col_ok = co < ((p.Nout + 3) & ~3);
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g_bias && col_ok) bias4 = *reinterpret_cast<const float4*>(g_bias + co);
+  const int m_last = p.M - 1;
+#pragma unroll
+  for (int hm = 0; hm < 2; ++hm) {
+#pragma unroll
+    for (int a0 = 0; a0 < TM; a0 += SUB) {
+      __syncthreads();
+      if (wm == hm) {
+#pragma unroll
+        for (int as = 0; as < SUB; ++as)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = as * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+            for (int b = 0; b < TN; ++b) stage[row * BN + wn * 32 * TN + b * 32 + il] = acc[a0 + as][b][r];
+          }
+      }
+      __syncthreads();
+      if (col_ok) {
+        constexpr int G = SWEEPS < 4 ? SWEEPS : 4;
+        const int base_row = m0 + hm * 32 * TM + a0 * 32;
+        auto sweep = [&](auto has_add, auto has_mask) {
+#pragma unroll
+          for (int s0 = 0; s0 < SWEEPS; s0 += G) {
+            float4 ad[G], mk[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+              const int m = min(base_row + e_r + RPI * (s0 + g), m_last);
+              if (has_add) ad[g] = *reinterpret_cast<const float4*>(g_addend + (long long)m * p.ld_add + co);
+              if (has_mask) mk[g] = *reinterpret_cast<const float4*>(g_mask + (long long)m * p.ld_mask + co);
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+              const int row = e_r + RPI * (s0 + g);
+              const int m = base_row + row;
+              float4 v = *reinterpret_cast<const float4*>(stage + row * BN + 4 * e_c4);
+              v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+              if (has_add) { v.x += ad[g].x; v.y += ad[g].y; v.z += ad[g].z; v.w += ad[g].w; }
+              if (has_mask) {
+                v.x = mk[g].x > 0.f ? v.x : 0.f; v.y = mk[g].y > 0.f ? v.y : 0.f;
+                v.z = mk[g].z > 0.f ? v.z : 0.f; v.w = mk[g].w > 0.f ? v.w : 0.f;
+              }
+              if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+              if (m <= m_last) *reinterpret_cast<float4*>(g_out + (long long)m * p.ld_out + co) = v;
+            }
+          }
+        };
+        if (g_addend != nullptr && g_mask != nullptr) sweep(std::true_type{}, std::true_type{});
+        else if (g_addend != nullptr) sweep(std::true_type{}, std::false_type{});
+        else if (g_mask != nullptr) sweep(std::false_type{}, std::true_type{});
+        else sweep(std::false_type{}, std::false_type{});
+      }
+    }
+  }
+}
+
+// ---- weight split: f32 HWIO [tap*cin + ci][ld_w] -> bf16 hi/lo planes in both k-contiguous layouts ----
+__global__ void split_weights_kernel(int taps, int cin, int cout, int ld_w, const float* __restrict__ w,
+                                     unsigned short* __restrict__ fwd_hi, unsigned short* __restrict__ fwd_lo, int cout_rows,
+                                     unsigned short* __restrict__ dg_hi, unsigned short* __restrict__ dg_lo, int dg_ld) {
+  // 32x32 (ci x co) tiles through LDS so that both layouts are written with contiguous rows
+  __shared__ unsigned short t_hi[32][33], t_lo[32][33];
+  const int tap = blockIdx.z, ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+  const int tx = threadIdx.x, ty = threadIdx.y;  // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int ci = ci0 + j, co = co0 + tx;
+    float v = 0.f;
+    if (ci < cin && co < cout) v = w[((long long)tap * cin + ci) * ld_w + co];
+    const __bf16 hh = (__bf16)v;
+    const __bf16 ll = (__bf16)(v - (float)hh);
+    const unsigned short uh = *reinterpret_cast<const unsigned short*>(&hh), ul = *reinterpret_cast<const unsigned short*>(&ll);
+    t_hi[j][tx] = uh;
+    t_lo[j][tx] = ul;
+    if (dg_hi && ci < cin && co < dg_ld) {  // bwd-data layout: [tap][ci][co], co contiguous
+      const long long o = ((long long)tap * cin + ci) * dg_ld + co;
+      dg_hi[o] = uh;
+      dg_lo[o] = ul;
+    }
+  }
+  __syncthreads();
+  if (fwd_hi) {
+    for (int j = ty; j < 32; j += 8) {  // forward layout: [tap][co][ci], ci contiguous
+      const int co = co0 + j, ci = ci0 + tx;
+      if (co < cout_rows && ci < cin) {
+        const long long o = ((long long)tap * cout_rows + co) * cin + ci;
+        fwd_hi[o] = t_hi[tx][j];
+        fwd_lo[o] = t_lo[tx][j];
+      }
+    }
+  }
+}
+
+extern "C" int pp_conv_split_weights_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* w, void* fwd_hi, void* fwd_lo,
+                                            void* dg_hi, void* dg_lo) {
+  PP_REQUIRE_CTX(ctx);
+  int rc = check_desc(ctx, d, "pp_conv_split_weights_bf16x3");
+  if (rc) return rc;
+  PP_CHECK_ARG(ctx, w && ((fwd_hi && fwd_lo) || (dg_hi && dg_lo)), PP_ERR_ARG, "pp_conv_split_weights_bf16x3: null tensor");
+  PP_CHECK_ARG(ctx, d->cin % 32 == 0, PP_ERR_SHAPE, "pp_conv_split_weights_bf16x3: cin %d must be a multiple of 32", d->cin);
+  const int taps = d->kh * d->kw;
+  const int dg_ld = (d->cout + 31) / 32 * 32;
+  dim3 grid((unsigned)((dg_ld + 31) / 32), (unsigned)((d->cin + 31) / 32), (unsigned)taps);
+  hipLaunchKernelGGL(split_weights_kernel, grid, dim3(32, 8), 0, ctx->stream, taps, d->cin, d->cout, d->ld_w, w,
+                     (unsigned short*)fwd_hi, (unsigned short*)fwd_lo, d->cout, (unsigned short*)dg_hi, (unsigned short*)dg_lo, dg_ld);
+  PP_CHECK_LAUNCH(ctx, "pp_conv_split_weights_bf16x3");
+  return PP_OK;
+}
+
+template <int TM, int TN>
+static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* whi, const void* wlo, int w_rows, int w_ld8) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  p.n_tiles_n = (p.Nout + BN - 1) / BN;
+  const int n_tiles_m = (p.M + BM - 1) / BM;
+  hipLaunchKernelGGL((igemm3_kernel<TM, TN>), dim3((unsigned)(n_tiles_m * p.n_tiles_n)), dim3(256), 0, st, p, p.src, (const uint4*)whi,
+                     (const uint4*)wlo, p.bias, p.addend, p.mask_src, p.out, w_rows, w_ld8);
+}
+
+static void pick_tile3(const pp_ctx* ctx, int M, int Nout, int* tm, int* tn) {
+  static const int cand[4][2] = {{2, 2}, {1, 2}, {2, 1}, {1, 1}};
+  static const double eff[4] = {1.0, 0.9, 0.9, 0.8};
+  static const int slots[4] = {3, 4, 4, 4};
+  const int cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
+  double best = 1e300;
+  for (int i = 0; i < 4; ++i) {
+    const int bm = 64 * cand[i][0], bn = 64 * cand[i][1];
+    const long long blocks = (long long)((M + bm - 1) / bm) * ((Nout + bn - 1) / bn);
+    const double t = est_rounds(blocks, slots[i], cus) * cand[i][0] * cand[i][1] / eff[i];
+    if (t < best * 0.999) {
+      best = t;
+      *tm = cand[i][0];
+      *tn = cand[i][1];
+    }
+  }
+  const char* e = getenv("PP_CONV3_TILE");
+  if (e && e[0] && e[1] == ',' && e[2]) {
+    *tm = e[0] - '0';
+    *tn = e[2] - '0';
+  }
+}
+
+static void dispatch3(pp_ctx* ctx, IgemmParams& p, const void* whi, const void* wlo, int w_rows, int w_ld8) {
+  int tm, tn;
+  pick_tile3(ctx, p.M, p.Nout, &tm, &tn);
+  if (tm == 2 && tn == 2) launch_igemm3<2, 2>(ctx->stream, p, whi, wlo, w_rows, w_ld8);
+  else if (tm == 1 && tn == 2) launch_igemm3<1, 2>(ctx->stream, p, whi, wlo, w_rows, w_ld8);
+  else if (tm == 2 && tn == 1) launch_igemm3<2, 1>(ctx->stream, p, whi, wlo, w_rows, w_ld8);
+  else launch_igemm3<1, 1>(ctx->stream, p, whi, wlo, w_rows, w_ld8);
+}
+
+extern "C" int pp_conv2d_nhwc_fwd_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const void* w_hi, const void* w_lo,
+                                         const float* bias, const float* residual, int ld_res, int relu, float* y) {
+  PP_REQUIRE_CTX(ctx);
+  int rc = check_desc(ctx, d, "pp_conv2d_nhwc_fwd_bf16x3");
+  if (rc) return rc;
+  PP_CHECK_ARG(ctx, x && w_hi && w_lo && y, PP_ERR_ARG, "pp_conv2d_nhwc_fwd_bf16x3: null tensor");
+  PP_CHECK_ARG(ctx, d->cin % 32 == 0 && d->ld_x % 4 == 0, PP_ERR_SHAPE, "pp_conv2d_nhwc_fwd_bf16x3: cin %d must be a multiple of 32", d->cin);
+  PP_CHECK_ARG(ctx, pp_is_aligned16(x) && pp_is_aligned16(w_hi) && pp_is_aligned16(w_lo) && pp_is_aligned16(y), PP_ERR_ALIGN,
+               "pp_conv2d_nhwc_fwd_bf16x3: tensors must be 16-byte aligned");
+  PP_CHECK_ARG(ctx, !residual || (ld_res % 4 == 0 && ld_res >= ((d->cout + 3) & ~3) && pp_is_aligned16(residual)), PP_ERR_SHAPE,
+               "pp_conv2d_nhwc_fwd_bf16x3: residual");
+  PP_CHECK_ARG(ctx, !bias || pp_is_aligned16(bias), PP_ERR_ALIGN, "pp_conv2d_nhwc_fwd_bf16x3: bias alignment");
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.src = x; p.out = y; p.bias = bias; p.addend = residual; p.mask_src = nullptr;
+  p.ld_src = d->ld_x; p.ld_w = d->ld_w; p.ld_out = d->ld_y; p.ld_add = ld_res; p.ld_mask = 0;
+  p.relu = relu;
+  p.n_seg = d->in.n_seg;
+  fill_segs(ctx, d, true, p.seg, &p.M);
+  p.Cred = d->cin; p.Nout = d->cout; p.w_tap_rows = d->cin;
+  p.kh = d->kh; p.kw = d->kw;
+  p.mul = d->stride; p.tsign = 1; p.off_y = -d->pad_t; p.off_x = -d->pad_l; p.div = 1;
+  dispatch3(ctx, p, w_hi, w_lo, d->cout, d->cin / 8);
+  PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_fwd_bf16x3");
+  return PP_OK;
+}
+
+extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* dy, const void* w_hi, const void* w_lo,
+                                              const float* addend, int ld_add, const float* relu_src, int ld_rs, float* dx) {
+  PP_REQUIRE_CTX(ctx);
+  int rc = check_desc(ctx, d, "pp_conv2d_nhwc_bwd_data_bf16x3");
+  if (rc) return rc;
+  PP_CHECK_ARG(ctx, dy && w_hi && w_lo && dx, PP_ERR_ARG, "pp_conv2d_nhwc_bwd_data_bf16x3: null tensor");
+  const int cred = (d->cout + 31) / 32 * 32;
+  PP_CHECK_ARG(ctx, d->cin % 16 == 0 && d->ld_y >= cred && d->ld_y % 4 == 0, PP_ERR_SHAPE,
+               "pp_conv2d_nhwc_bwd_data_bf16x3: dy needs ld_y >= %d (cout rounded up to 32, zero padded)", cred);
+  PP_CHECK_ARG(ctx, pp_is_aligned16(dy) && pp_is_aligned16(w_hi) && pp_is_aligned16(w_lo) && pp_is_aligned16(dx), PP_ERR_ALIGN,
+               "pp_conv2d_nhwc_bwd_data_bf16x3: tensors must be 16-byte aligned");
+  PP_CHECK_ARG(ctx, (!addend || (ld_add >= d->cin && ld_add % 4 == 0 && pp_is_aligned16(addend))) &&
+                        (!relu_src || (ld_rs >= d->cin && ld_rs % 4 == 0 && pp_is_aligned16(relu_src))),
+               PP_ERR_SHAPE, "pp_conv2d_nhwc_bwd_data_bf16x3: addend / relu_src");
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.src = dy; p.out = dx; p.bias = nullptr; p.addend = addend; p.mask_src = relu_src;
+  p.ld_src = d->ld_y; p.ld_w = d->ld_w; p.ld_out = d->ld_x; p.ld_add = ld_add; p.ld_mask = ld_rs;
+  p.relu = 0;
+  p.n_seg = d->in.n_seg;
+  fill_segs(ctx, d, false, p.seg, &p.M);
+  p.Cred = cred; p.Nout = d->cin; p.w_tap_rows = d->cin;
+  p.kh = d->kh; p.kw = d->kw;
+  p.mul = 1; p.tsign = -1; p.off_y = d->pad_t; p.off_x = d->pad_l; p.div = d->stride;
+  dispatch3(ctx, p, w_hi, w_lo, d->cin, cred / 8);
+  PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_data_bf16x3");
+  return PP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// weight gradient on the bf16 matrix cores:  dw[tap][ci][co] += sum_m x[gather(m,tap)][ci] * dy[m][co]
+// The reduction index is the pixel m, but NHWC tensors are channel-contiguous, so both MFMA operands need a
+// transpose: the 32-pixel x 128-channel f32 tiles are split to bf16 (hi, lo) while they are staged into LDS
+// pixel-major ([pixel][channel], pitch = row + 64 B) and the k-contiguous fragments are fetched with the
+// transposing LDS read ds_read_b64_tr_b16 (two reads = 8 pixels of one channel per lane; lane map verified by
+// tools/ubench/tr16_check.hip).  With the +64 B pitch the four rows of a 16-lane read group fall in four disjoint
+// 16-dword bank windows: conflict free.  Split over pixel ranges + f32 atomics like wgrad_kernel (conv.hip).
+typedef short shortx4 __attribute__((ext_vector_type(4)));
+
+struct Wgrad3Params {
+  int ld_src, ld_dy, ld_w;
+  int M, n_seg;
+  SegGeo seg[PP_MAX_SEG];
+  int Cin, Cout;
+  int kh, kw, stride, pad_t, pad_l;
+  int k_tiles_per_tap, n_tiles_k, n_tiles_n, splits, rows_per_split;
+};
+
+__device__ __forceinline__ void split4(const float4& v4, uint2* out_hi, uint2* out_lo) {
+  const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  bf16x4 h, l;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const __bf16 hh = (__bf16)v[j];
+    h[j] = hh;
+    l[j] = (__bf16)(v[j] - (float)hh);
+  }
+  *out_hi = *reinterpret_cast<uint2*>(&h);
+  *out_lo = *reinterpret_cast<uint2*>(&l);
+}
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned short* lds, int elem_off0, int elem_off1) {
+  typedef __attribute__((address_space(3))) shortx4 lds_s4;
+  shortx4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(lds + elem_off0));
+  shortx4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(lds + elem_off1));
+  typedef short shortx8 __attribute__((ext_vector_type(8)));
+  shortx8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return *reinterpret_cast<bf16x8*>(&v);
+}
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256, (TM * TN == 4) ? 2 : 3) void wgrad3_kernel(const Wgrad3Params p, const float* __restrict__ g_src,
+                                                                            const float* __restrict__ g_dy, float* __restrict__ g_dw,
+                                                                            float* __restrict__ g_dbias) {
+  constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32;
+  constexpr int PA = BM + 32, PB = BN + 32;  // LDS pitches in bf16 elements (row + 64 bytes)
+  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BK * (PA + PB)];
+  unsigned short* Xhi = smem;
+  unsigned short* Xlo = Xhi + BK * PA;
+  unsigned short* Ghi = Xlo + BK * PA;
+  unsigned short* Glo = Ghi + BK * PB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int b = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int tile_n = b % p.n_tiles_n;
+  b /= p.n_tiles_n;
+  const int tile_k = b % p.n_tiles_k;
+  const int split = b / p.n_tiles_k;
+  const int tap = tile_k / p.k_tiles_per_tap;
+  const int ci0 = (tile_k - tap * p.k_tiles_per_tap) * BM;
+  const int ty = tap / p.kw, tx = tap - ty * p.kw;
+  const int n0 = tile_n * BN;
+  const int m_begin = split * p.rows_per_split;
+  const int m_end = min(p.M, m_begin + p.rows_per_split);
+  const int n_steps = (m_end - m_begin + BK - 1) / BK;
+
+  // staging: 8 threads per pixel row, thread loads the float4 channel quads q8 + 8*j
+  const int prow = tid >> 3, q8 = tid & 7;
+  constexpr int QA = BM / 32, QB = BN / 32;  // quads per thread
+  struct WRow { int m, n, y, x, seg_end, sb, OH, OW, SH, SW; } w;
+  auto decode = [&](int m) {
+    w.m = m;
+    int rbeg = p.seg[0].row_begin;
+    w.sb = p.seg[0].src_row_begin; w.OH = p.seg[0].OH; w.OW = p.seg[0].OW; w.SH = p.seg[0].SH; w.SW = p.seg[0].SW;
+    w.seg_end = p.n_seg > 1 ? p.seg[1].row_begin : p.M;
+    for (int s = 1; s < p.n_seg; ++s) {
+      if (m >= p.seg[s].row_begin) {
+        rbeg = p.seg[s].row_begin; w.sb = p.seg[s].src_row_begin; w.OH = p.seg[s].OH; w.OW = p.seg[s].OW;
+        w.SH = p.seg[s].SH; w.SW = p.seg[s].SW;
+        w.seg_end = (s + 1 < p.n_seg) ? p.seg[s + 1].row_begin : p.M;
+      }
+    }
+    const int local = m < p.M ? m - rbeg : 0;
+    const int hw = w.OH * w.OW;
+    w.n = local / hw;
+    const int rem = local - w.n * hw;
+    w.y = rem / w.OW;
+    w.x = rem - w.y * w.OW;
+  };
+  decode(m_begin + prow);
+
+  float4 ra[QA], rb[QB];
+  float4 bsum[QB];
+#pragma unroll
+  for (int j = 0; j < QB; ++j) bsum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool do_bias = (g_dbias != nullptr) && (tile_k == 0);
+
+  auto load_step = [&]() {
+    const int sy = w.y * p.stride + ty - p.pad_t;
+    const int sx = w.x * p.stride + tx - p.pad_l;
+    const bool in_rng = w.m < m_end;
+    const bool ok = in_rng && ((unsigned)sy < (unsigned)w.SH) && ((unsigned)sx < (unsigned)w.SW);
+    const float* src = g_src + (long long)(w.sb + w.n * w.SH * w.SW + sy * w.SW + sx) * p.ld_src + ci0;
+#pragma unroll
+    for (int j = 0; j < QA; ++j)
+      ra[j] = ok ? *reinterpret_cast<const float4*>(src + 4 * (q8 + 8 * j)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* dyr = g_dy + (long long)w.m * p.ld_dy + n0;
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+      const int c = n0 + 4 * (q8 + 8 * j);
+      rb[j] = (in_rng && c < p.ld_dy) ? *reinterpret_cast<const float4*>(dyr + 4 * (q8 + 8 * j)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // advance this thread's pixel row by one step
+    const int m2 = w.m + BK;
+    if (m2 >= w.seg_end) {
+      decode(m2);
+    } else {
+      w.m = m2;
+      w.x += BK;
+      while (w.x >= w.OW) { w.x -= w.OW; ++w.y; }
+      while (w.y >= w.OH) { w.y -= w.OH; ++w.n; }
+    }
+  };
+  auto store_step = [&]() {
+#pragma unroll
+    for (int j = 0; j < QA; ++j) {
+      uint2 hi, lo;
+      split4(ra[j], &hi, &lo);
+      const int off = prow * PA + 4 * (q8 + 8 * j);
+      *reinterpret_cast<uint2*>(Xhi + off) = hi;
+      *reinterpret_cast<uint2*>(Xlo + off) = lo;
+    }
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+      uint2 hi, lo;
+      split4(rb[j], &hi, &lo);
+      const int off = prow * PB + 4 * (q8 + 8 * j);
+      *reinterpret_cast<uint2*>(Ghi + off) = hi;
+      *reinterpret_cast<uint2*>(Glo + off) = lo;
+      if (do_bias) { bsum[j].x += rb[j].x; bsum[j].y += rb[j].y; bsum[j].z += rb[j].z; bsum[j].w += rb[j].w; }
+    }
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int c = 0; c < TN; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+  // transposed-read lane roles (16-lane groups): group g -> columns 16*(g&1).., pixel half h = g>>1
+  const int grp = lane >> 4, gi = lane & 15, gq = gi >> 2, gp = gi & 3;
+  const int cbase = 16 * (grp & 1), hh = grp >> 1;
+  const int il = lane & 31, h = lane >> 5;
+
+  if (n_steps > 0) {
+    load_step();
+    store_step();
+  }
+  __syncthreads();
+  for (int step = 0; step < n_steps; ++step) {
+    const bool more = step + 1 < n_steps;
+    if (more) load_step();
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      const int row0 = 16 * s + 8 * hh + gq;  // pixel row this lane addresses in the first transposed read
+      bf16x8 xh[TM], xl[TM], gh[TN], gl[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const int col = wm * 32 * TM + a * 32 + cbase + 4 * gp;
+        xh[a] = tr_frag(Xhi, row0 * PA + col, (row0 + 4) * PA + col);
+        xl[a] = tr_frag(Xlo, row0 * PA + col, (row0 + 4) * PA + col);
+      }
+#pragma unroll
+      for (int c = 0; c < TN; ++c) {
+        const int col = wn * 32 * TN + c * 32 + cbase + 4 * gp;
+        gh[c] = tr_frag(Ghi, row0 * PB + col, (row0 + 4) * PB + col);
+        gl[c] = tr_frag(Glo, row0 * PB + col, (row0 + 4) * PB + col);
+      }
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int c = 0; c < TN; ++c) {
+          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[a], gh[c], acc[a][c], 0, 0, 0);
+          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[a], gl[c], acc[a][c], 0, 0, 0);
+          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[a], gh[c], acc[a][c], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (more) {
+      store_step();
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = ci0 + wm * 32 * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      float* dst = g_dw + (long long)(tap * p.Cin + ci) * p.ld_w;
+#pragma unroll
+      for (int c = 0; c < TN; ++c) {
+        const int co = n0 + wn * 32 * TN + c * 32 + il;
+        if (co < p.Cout) atomicAdd(dst + co, acc[a][c][r]);
+      }
+    }
+  }
+  if (do_bias) {
+    // 32 threads (one per pixel row of the step) hold partial sums of the same channel quad: reduce through LDS
+    float* red = reinterpret_cast<float*>(smem);  // [32][BN] floats <= LDS size
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < QB; ++j) *reinterpret_cast<float4*>(red + prow * BN + 4 * (q8 + 8 * j)) = bsum[j];
+    __syncthreads();
+    if (tid < BN) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) s += red[r * BN + tid];
+      if (n0 + tid < p.Cout) atomicAdd(g_dbias + n0 + tid, s);
+    }
+  }
+}
+
+template <int TM, int TN>
+static void launch_wgrad3(pp_ctx* ctx, Wgrad3Params& p, const float* x, const float* dy, float* dw, float* dbias) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  p.k_tiles_per_tap = p.Cin / BM;
+  p.n_tiles_k = p.kh * p.kw * p.k_tiles_per_tap;
+  p.n_tiles_n = (p.Cout + BN - 1) / BN;
+  const int tiles = p.n_tiles_k * p.n_tiles_n;
+  const int cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
+  int max_splits = (p.M + 511) / 512;  // at least 16 reduction steps of 32 rows per workgroup
+  if (max_splits < 1) max_splits = 1;
+  if (max_splits > 64) max_splits = 64;
+  const int slots = (TM * TN == 4) ? 2 : 3;
+  const double tile_work = (double)(TM * TN) / 4.0;
+  const double atomic_us_per_split = (double)tiles * BM * BN * 4.0 / 1.3e6;
+  int splits = 1;
+  double best = 1e300;
+  for (int sp = 1; sp <= max_splits; ++sp) {
+    const double steps = (double)((p.M + sp - 1) / sp + 31) / 32.0;
+    const double cost = est_rounds((long long)tiles * sp, slots, cus) * steps * tile_work * 0.8 + atomic_us_per_split * sp;
+    if (cost < best * 0.995) {
+      best = cost;
+      splits = sp;
+    }
+  }
+  int rps = (p.M + splits - 1) / splits;
+  rps = (rps + 31) / 32 * 32;
+  splits = (p.M + rps - 1) / rps;
+  p.splits = splits;
+  p.rows_per_split = rps;
+  hipLaunchKernelGGL((wgrad3_kernel<TM, TN>), dim3((unsigned)(tiles * splits)), dim3(256), 0, ctx->stream, p, x, dy, dw, dbias);
+}
+
+extern "C" int pp_conv2d_nhwc_bwd_weight_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const float* dy, float* dw,
+                                                float* dbias) {
+  PP_REQUIRE_CTX(ctx);
+  int rc = check_desc(ctx, d, "pp_conv2d_nhwc_bwd_weight_bf16x3");
+  if (rc) return rc;
+  PP_CHECK_ARG(ctx, x && dy && dw, PP_ERR_ARG, "pp_conv2d_nhwc_bwd_weight_bf16x3: null tensor");
+  PP_CHECK_ARG(ctx, d->cin % 64 == 0, PP_ERR_SHAPE, "pp_conv2d_nhwc_bwd_weight_bf16x3: cin %d must be a multiple of 64", d->cin);
+  PP_CHECK_ARG(ctx, d->ld_y % 4 == 0 && d->ld_x % 4 == 0, PP_ERR_SHAPE, "pp_conv2d_nhwc_bwd_weight_bf16x3: leading dims must be multiples of 4");
+  PP_CHECK_ARG(ctx, pp_is_aligned16(x) && pp_is_aligned16(dy), PP_ERR_ALIGN, "pp_conv2d_nhwc_bwd_weight_bf16x3: tensors must be 16-byte aligned");
+  Wgrad3Params p;
+  memset(&p, 0, sizeof(p));
+  p.ld_src = d->ld_x; p.ld_dy = d->ld_y; p.ld_w = d->ld_w;
+  p.n_seg = d->in.n_seg;
+  fill_segs(ctx, d, true, p.seg, &p.M);
+  p.Cin = d->cin; p.Cout = d->cout;
+  p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+  const bool big_k = (d->cin % 128 == 0);
+  const bool big_n = ((d->cout + 127) / 128 * 128) <= ((d->cout + 63) / 64 * 64);
+  if (big_k && big_n) launch_wgrad3<2, 2>(ctx, p, x, dy, dw, dbias);
+  else if (big_k) launch_wgrad3<2, 1>(ctx, p, x, dy, dw, dbias);
+  else if (big_n) launch_wgrad3<1, 2>(ctx, p, x, dy, dw, dbias);
+  else launch_wgrad3<1, 1>(ctx, p, x, dy, dw, dbias);
+  PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_weight_bf16x3");
+  return PP_OK;
+}

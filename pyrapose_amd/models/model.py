@@ -116,6 +116,7 @@ class PyraPoseModel(object):
         self._weights = W
         if self._engine is not None:
             self._engine.params.load(W)
+            self._engine.refresh_planes()
 
     def save_weights(self, filepath):
         np.savez(filepath, **self.get_weights_dict())

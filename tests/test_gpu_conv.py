@@ -222,3 +222,105 @@ def test_pointwise_ops(ctx):
     out = torch.empty_like(a).cuda()
     ops.add_n(ctx, a.cuda(), a.cuda(), a.cuda(), out)
     assert torch.equal(out.cpu(), (a + a) + a)
+
+
+BF3_CASES = [c for c in CASES if c[3] % 32 == 0 and c[4] % 32 == 0]
+
+
+@pytest.mark.parametrize("case", BF3_CASES, ids=[c[0] for c in BF3_CASES])
+def test_conv_bf16x3_fwd_bwd_data(ctx, case):
+    """3 x bf16 MFMA path: float32-class accuracy (<= 1e-4 of the output magnitude, ~2^-16 per product)."""
+    from pyrapose_amd import ops
+    name, B, shapes, cin, cout, k, stride, pad, ld_y, xs, w, bias = _setup(case, seed=3)
+    ref = ref_conv(xs, w, bias, stride, pad)
+    out_shapes = [(r.shape[1], r.shape[2]) for r in ref]
+    if pad == "same":
+        pt, pl = tf_same(shapes[0][0], k, stride)[0], tf_same(shapes[0][1], k, stride)[0]
+    else:
+        pt = pl = pad
+    ld_y = ld_y or ((cout + 15) // 16 * 16)
+    wd, ld_w = _device_weight(w, cout)
+    x = _cat_rows(xs)
+    d = ops.make_conv_desc(B, shapes, out_shapes, cin, cout, k, stride, pt, pl, cin, ld_y, ld_w)
+    taps = k * k
+    u16 = dict(dtype=torch.int16, device="cuda")
+    fh, fl = torch.zeros((taps, cout, cin), **u16), torch.zeros((taps, cout, cin), **u16)
+    dh, dl = torch.zeros((taps, cin, cout), **u16), torch.zeros((taps, cin, cout), **u16)
+    ops.conv_split_weights3(ctx, d, wd, fh, fl, dh, dl)
+    # the planes reproduce the weights to ~2^-17
+    back = (fh.view(torch.bfloat16).float() + fl.view(torch.bfloat16).float()).permute(0, 2, 1).reshape(taps * cin, cout).cpu().numpy()
+    assert rel_err(back, w.reshape(-1, cout)) < 2e-5
+    back = (dh.view(torch.bfloat16).float() + dl.view(torch.bfloat16).float()).reshape(taps * cin, cout).cpu().numpy()
+    assert rel_err(back, w.reshape(-1, cout)) < 2e-5
+    rows_out = sum(B * h * ww for h, ww in out_shapes)
+    rng = np.random.default_rng(1)
+    res = [torch.as_tensor(rng.standard_normal(tuple(r.shape)), dtype=torch.float64) for r in ref]
+    y = torch.full((rows_out, ld_y), float("nan"), dtype=torch.float32, device="cuda")
+    bd = torch.zeros((ld_w,), dtype=torch.float32)
+    bd[:cout] = torch.as_tensor(bias, dtype=torch.float32)
+    ops.conv_fwd3(ctx, d, x, fh, fl, bd.cuda(), _cat_rows(res, ld_y), True, y)
+    want = torch.cat([torch.relu(r + q).reshape(-1, cout) for r, q in zip(ref, res)], dim=0).numpy()
+    e = rel_err(y.cpu().numpy()[:, :cout], want)
+    assert e < 1e-4, e
+    # bwd-data against float64 autograd
+    xg = [t.clone().requires_grad_(True) for t in xs]
+    wt = torch.as_tensor(w, dtype=torch.float64)
+    outs = []
+    for t in xg:
+        xt = t.permute(0, 3, 1, 2)
+        if pad == "same":
+            a, b_, _ = tf_same(xt.shape[2], k, stride)
+            c_, e_, _ = tf_same(xt.shape[3], k, stride)
+        else:
+            a = b_ = c_ = e_ = pad
+        outs.append(F.conv2d(F.pad(xt, (c_, e_, a, b_)), wt.permute(3, 2, 0, 1), None, stride=stride).permute(0, 2, 3, 1))
+    gys = [torch.as_tensor(rng.standard_normal(tuple(o.shape)), dtype=torch.float64) for o in outs]
+    gx_ref = torch.autograd.grad(sum((o * g).sum() for o, g in zip(outs, gys)), xg)
+    gy = _cat_rows(gys, ld_y)
+    addend = [torch.as_tensor(rng.standard_normal(tuple(t.shape)), dtype=torch.float64) for t in xs]
+    rsrc = [torch.as_tensor(rng.standard_normal(tuple(t.shape)), dtype=torch.float64) for t in xs]
+    dx = torch.full((x.shape[0], cin), float("nan"), dtype=torch.float32, device="cuda")
+    ops.conv_bwd_data3(ctx, d, gy, dh, dl, _cat_rows(addend), _cat_rows(rsrc), dx)
+    want = torch.cat([((g + a) * (r > 0)).reshape(-1, cin) for g, a, r in zip(gx_ref, addend, rsrc)], dim=0).numpy()
+    e = rel_err(dx.cpu().numpy(), want)
+    assert e < 1e-4, e
+
+
+WG3_CASES = [c for c in CASES if c[3] % 64 == 0]
+
+
+@pytest.mark.parametrize("case", WG3_CASES, ids=[c[0] for c in WG3_CASES])
+def test_conv_bf16x3_bwd_weight(ctx, case):
+    """Weight gradient on the bf16 matrix cores (transposed LDS reads) vs float64 autograd."""
+    from pyrapose_amd import ops
+    name, B, shapes, cin, cout, k, stride, pad, ld_y, xs, w, bias = _setup(case, seed=5)
+    xg = [t.clone() for t in xs]
+    wt = torch.as_tensor(w, dtype=torch.float64).requires_grad_(True)
+    outs = []
+    for t in xg:
+        xt = t.permute(0, 3, 1, 2)
+        if pad == "same":
+            a, b_, _ = tf_same(xt.shape[2], k, stride)
+            c_, e_, _ = tf_same(xt.shape[3], k, stride)
+        else:
+            a = b_ = c_ = e_ = pad
+        outs.append(F.conv2d(F.pad(xt, (c_, e_, a, b_)), wt.permute(3, 2, 0, 1), None, stride=stride).permute(0, 2, 3, 1))
+    out_shapes = [(o.shape[1], o.shape[2]) for o in outs]
+    rng = np.random.default_rng(2)
+    gys = [torch.as_tensor(rng.standard_normal(tuple(o.shape)), dtype=torch.float64) for o in outs]
+    gw_ref, = torch.autograd.grad(sum((o * g).sum() for o, g in zip(outs, gys)), [wt])
+    if pad == "same":
+        pt, pl = tf_same(shapes[0][0], k, stride)[0], tf_same(shapes[0][1], k, stride)[0]
+    else:
+        pt = pl = pad
+    ld_y = ld_y or ((cout + 15) // 16 * 16)
+    ld_w = (cout + 15) // 16 * 16
+    d = ops.make_conv_desc(B, shapes, out_shapes, cin, cout, k, stride, pt, pl, cin, ld_y, ld_w)
+    dw = torch.zeros((k * k * cin, ld_w), dtype=torch.float32, device="cuda")
+    db = torch.zeros((ld_w,), dtype=torch.float32, device="cuda")
+    ops.conv_bwd_weight3(ctx, d, _cat_rows(xs), _cat_rows(gys, ld_y), dw, db)
+    e = rel_err(dw.cpu().numpy()[:, :cout], gw_ref.reshape(-1, cout).numpy())
+    assert e < 1e-4, e
+    assert np.all(dw.cpu().numpy()[:, cout:] == 0)
+    db_ref = sum(g.reshape(-1, cout).sum(0) for g in gys).numpy()
+    assert rel_err(db.cpu().numpy()[:cout], db_ref) < 5e-5

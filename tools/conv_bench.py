@@ -61,7 +61,17 @@ def main():
         db = torch.zeros((ld_w,), device="cuda")
         bias = torch.zeros((ld_w,), device="cuda")
         flops = 2.0 * rows * k * k * cin * cout
-        fns = {"fwd": lambda: ops.conv_fwd(ctx, d, x, w, bias, None, True, y),
+        taps = k * k
+        i16 = dict(dtype=torch.int16, device="cuda")
+        if cin % 32 == 0 and cout % 32 == 0:
+            fh, fl = torch.zeros((taps, cout, cin), **i16), torch.zeros((taps, cout, cin), **i16)
+            dh, dl = torch.zeros((taps, cin, cout), **i16), torch.zeros((taps, cin, cout), **i16)
+            ops.conv_split_weights3(ctx, d, w, fh, fl, dh, dl)
+        fns = {"fwd3": lambda: ops.conv_fwd3(ctx, d, x, fh, fl, bias, None, True, y),
+               "dgrad3": lambda: ops.conv_bwd_data3(ctx, d, dy, dh, dl, None, x, dx),
+               "wgrad3": lambda: ops.conv_bwd_weight3(ctx, d, x, dy, dw, db),
+               "split3": lambda: ops.conv_split_weights3(ctx, d, w, fh, fl, dh, dl),
+               "fwd": lambda: ops.conv_fwd(ctx, d, x, w, bias, None, True, y),
                "dgrad": lambda: ops.conv_bwd_data(ctx, d, dy, w, None, x, dx),
                "wgrad": lambda: ops.conv_bwd_weight(ctx, d, x, dy, dw, db)}
         for mode in args.mode.split(","):
