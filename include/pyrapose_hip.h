@@ -101,17 +101,20 @@ int pp_conv2d_nhwc_bwd_weight(pp_ctx* ctx, const pp_conv_desc* d, const float* x
  * Any of the plane pairs may be NULL in pp_conv_split_weights_bf16x3. */
 int pp_conv_split_weights_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* w, void* fwd_hi, void* fwd_lo,
                                  void* dgrad_hi, void* dgrad_lo);
-int pp_conv2d_nhwc_fwd_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const void* w_fwd_hi,
-                              const void* w_fwd_lo, const float* bias, const float* residual, int ld_res,
-                              int relu, float* y);
+/* f32 tensor of n elements (n % 8 == 0) -> bf16 (hi, lo) planes with the same [rows][ld] geometry.  Convs that are
+ * given planes for their gathered operand skip the conversion inside the kernel (the f32 pointer may then be NULL). */
+int pp_split_planes_bf16x3(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo);
+int pp_conv2d_nhwc_fwd_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const void* x_hi, const void* x_lo,
+                              const void* w_fwd_hi, const void* w_fwd_lo, const float* bias, const float* residual,
+                              int ld_res, int relu, float* y);
 /* dy rows need ld_y >= cout rounded up to 32 with zero padding. */
-int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* dy, const void* w_dgrad_hi,
-                                   const void* w_dgrad_lo, const float* addend, int ld_add,
-                                   const float* relu_src, int ld_rs, float* dx);
-
-/* dw += x^T (*) dy with both operands split to bf16 (hi, lo) on the fly (no weight planes involved); same contract
- * as pp_conv2d_nhwc_bwd_weight, cin % 64 == 0. */
+int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* dy, const void* dy_hi,
+                                   const void* dy_lo, const void* w_dgrad_hi, const void* w_dgrad_lo,
+                                   const float* addend, int ld_add, const float* relu_src, int ld_rs, float* dx);
+/* dw += x^T (*) dy; operands either f32 (split on the fly) or all four planes; same contract as
+ * pp_conv2d_nhwc_bwd_weight, cin % 64 == 0. */
 int pp_conv2d_nhwc_bwd_weight_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const float* dy,
+                                     const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo,
                                      float* dw, float* dbias);
 
 /* ---- pooling / resampling / pointwise --------------------------------------------------

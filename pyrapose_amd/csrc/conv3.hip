@@ -29,9 +29,12 @@ __device__ __forceinline__ void split8(const float4& lo4, const float4& hi4, uin
   *out_lo = *reinterpret_cast<uint4*>(&l);
 }
 
-template <int TM, int TN>
+// AP: the gathered operand comes from pre-split bf16 (hi, lo) planes (pp_split_planes_bf16x3, same [rows][ld]
+// geometry as the f32 tensor) instead of being split from f32 while staging: no conversion VALU in the loop.
+template <int TM, int TN, bool AP>
 __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3_kernel(
-    const IgemmParams p, const float* __restrict__ g_src, const uint4* __restrict__ g_whi, const uint4* __restrict__ g_wlo,
+    const IgemmParams p, const float* __restrict__ g_src, const uint4* __restrict__ g_ahi, const uint4* __restrict__ g_alo,
+    const uint4* __restrict__ g_whi, const uint4* __restrict__ g_wlo,
     const float* __restrict__ g_bias, const float* __restrict__ g_addend, const float* __restrict__ g_mask,
     float* __restrict__ g_out, int w_rows, int w_ld8) {
   constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, NO = BK / 8;
@@ -60,6 +63,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3_kernel(
   const int n_steps = n_taps * (p.Cred / BK);
 
   float4 ra[TM][2];
+  uint4 rah[TM], ral[TM];
   uint4 rbh[TN], rbl[TN];
   int tap = 0, ty = 0, tx = 0, red0 = 0;
 
@@ -70,7 +74,16 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3_kernel(
   auto load_step = [&]() {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      if (a_ok[i]) {
+      if (AP) {
+        if (a_ok[i]) {
+          const long long o8 = ((a_off[i] + red0) >> 3) + oct;
+          rah[i] = g_ahi[o8];
+          ral[i] = g_alo[o8];
+        } else {
+          rah[i] = make_uint4(0u, 0u, 0u, 0u);
+          ral[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+      } else if (a_ok[i]) {
         const float4* s4 = reinterpret_cast<const float4*>(g_src + a_off[i] + red0 + 8 * oct);
         ra[i][0] = s4[0];
         ra[i][1] = s4[1];
@@ -106,7 +119,12 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3_kernel(
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       uint4 hi, lo;
-      split8(ra[i][0], ra[i][1], &hi, &lo);
+      if (AP) {
+        hi = rah[i];
+        lo = ral[i];
+      } else {
+        split8(ra[i][0], ra[i][1], &hi, &lo);
+      }
       const int slot = oct * BM + ((r0 + 64 * i + 2 * oct) & (BM - 1));
       Ahi[slot] = hi;
       Alo[slot] = lo;
@@ -134,6 +152,8 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3_kernel(
   store_step();
   __syncthreads();
 
+  // (a double-buffered LDS variant -- one barrier per step, 64 KB per workgroup -- measured 15-20 % SLOWER:
+  //  the occupancy drop from 3 to 2 workgroups per CU costs more than the second barrier)
   for (int step = 0; step < n_steps; ++step) {
     const bool more = step + 1 < n_steps;
     if (more) {
@@ -244,6 +264,29 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3_kernel(
   }
 }
 
+// ---- activation / gradient split: f32 [rows][ld] -> bf16 hi/lo planes with the same geometry ----
+__global__ void split_planes_kernel(size_t n8, const float4* __restrict__ src, uint4* __restrict__ hi, uint4* __restrict__ lo) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    uint4 h, l;
+    split8(src[2 * i], src[2 * i + 1], &h, &l);
+    hi[i] = h;
+    lo[i] = l;
+  }
+}
+
+extern "C" int pp_split_planes_bf16x3(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, src && hi && lo && n % 8 == 0, PP_ERR_ARG, "pp_split_planes_bf16x3: n must be a multiple of 8");
+  PP_CHECK_ARG(ctx, pp_is_aligned16(src) && pp_is_aligned16(hi) && pp_is_aligned16(lo), PP_ERR_ALIGN, "pp_split_planes_bf16x3: alignment");
+  if (n == 0) return PP_OK;
+  size_t blocks = (n / 8 + 255) / 256;
+  const size_t cap = (size_t)(ctx->n_cu > 0 ? ctx->n_cu : 256) * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, n / 8, (const float4*)src, (uint4*)hi, (uint4*)lo);
+  PP_CHECK_LAUNCH(ctx, "pp_split_planes_bf16x3");
+  return PP_OK;
+}
+
 // ---- weight split: f32 HWIO [tap*cin + ci][ld_w] -> bf16 hi/lo planes in both k-contiguous layouts ----
 __global__ void split_weights_kernel(int taps, int cin, int cout, int ld_w, const float* __restrict__ w,
                                      unsigned short* __restrict__ fwd_hi, unsigned short* __restrict__ fwd_lo, int cout_rows,
@@ -297,12 +340,18 @@ extern "C" int pp_conv_split_weights_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, 
 }
 
 template <int TM, int TN>
-static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* whi, const void* wlo, int w_rows, int w_ld8) {
+static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const void* alo, const void* whi, const void* wlo, int w_rows,
+                          int w_ld8) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   p.n_tiles_n = (p.Nout + BN - 1) / BN;
   const int n_tiles_m = (p.M + BM - 1) / BM;
-  hipLaunchKernelGGL((igemm3_kernel<TM, TN>), dim3((unsigned)(n_tiles_m * p.n_tiles_n)), dim3(256), 0, st, p, p.src, (const uint4*)whi,
-                     (const uint4*)wlo, p.bias, p.addend, p.mask_src, p.out, w_rows, w_ld8);
+  const dim3 grid((unsigned)(n_tiles_m * p.n_tiles_n));
+  if (ahi)
+    hipLaunchKernelGGL((igemm3_kernel<TM, TN, true>), grid, dim3(256), 0, st, p, p.src, (const uint4*)ahi, (const uint4*)alo,
+                       (const uint4*)whi, (const uint4*)wlo, p.bias, p.addend, p.mask_src, p.out, w_rows, w_ld8);
+  else
+    hipLaunchKernelGGL((igemm3_kernel<TM, TN, false>), grid, dim3(256), 0, st, p, p.src, (const uint4*)nullptr, (const uint4*)nullptr,
+                       (const uint4*)whi, (const uint4*)wlo, p.bias, p.addend, p.mask_src, p.out, w_rows, w_ld8);
 }
 
 static void pick_tile3(const pp_ctx* ctx, int M, int Nout, int* tm, int* tn) {
@@ -328,23 +377,27 @@ static void pick_tile3(const pp_ctx* ctx, int M, int Nout, int* tm, int* tn) {
   }
 }
 
-static void dispatch3(pp_ctx* ctx, IgemmParams& p, const void* whi, const void* wlo, int w_rows, int w_ld8) {
+static void dispatch3(pp_ctx* ctx, IgemmParams& p, const void* ahi, const void* alo, const void* whi, const void* wlo, int w_rows,
+                      int w_ld8) {
   int tm, tn;
   pick_tile3(ctx, p.M, p.Nout, &tm, &tn);
-  if (tm == 2 && tn == 2) launch_igemm3<2, 2>(ctx->stream, p, whi, wlo, w_rows, w_ld8);
-  else if (tm == 1 && tn == 2) launch_igemm3<1, 2>(ctx->stream, p, whi, wlo, w_rows, w_ld8);
-  else if (tm == 2 && tn == 1) launch_igemm3<2, 1>(ctx->stream, p, whi, wlo, w_rows, w_ld8);
-  else launch_igemm3<1, 1>(ctx->stream, p, whi, wlo, w_rows, w_ld8);
+  if (tm == 2 && tn == 2) launch_igemm3<2, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8);
+  else if (tm == 1 && tn == 2) launch_igemm3<1, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8);
+  else if (tm == 2 && tn == 1) launch_igemm3<2, 1>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8);
+  else launch_igemm3<1, 1>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8);
 }
 
-extern "C" int pp_conv2d_nhwc_fwd_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const void* w_hi, const void* w_lo,
-                                         const float* bias, const float* residual, int ld_res, int relu, float* y) {
+extern "C" int pp_conv2d_nhwc_fwd_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const void* x_hi, const void* x_lo,
+                                         const void* w_hi, const void* w_lo, const float* bias, const float* residual, int ld_res,
+                                         int relu, float* y) {
   PP_REQUIRE_CTX(ctx);
   int rc = check_desc(ctx, d, "pp_conv2d_nhwc_fwd_bf16x3");
   if (rc) return rc;
-  PP_CHECK_ARG(ctx, x && w_hi && w_lo && y, PP_ERR_ARG, "pp_conv2d_nhwc_fwd_bf16x3: null tensor");
-  PP_CHECK_ARG(ctx, d->cin % 32 == 0 && d->ld_x % 4 == 0, PP_ERR_SHAPE, "pp_conv2d_nhwc_fwd_bf16x3: cin %d must be a multiple of 32", d->cin);
-  PP_CHECK_ARG(ctx, pp_is_aligned16(x) && pp_is_aligned16(w_hi) && pp_is_aligned16(w_lo) && pp_is_aligned16(y), PP_ERR_ALIGN,
+  PP_CHECK_ARG(ctx, (x || (x_hi && x_lo)) && w_hi && w_lo && y, PP_ERR_ARG, "pp_conv2d_nhwc_fwd_bf16x3: null tensor");
+  PP_CHECK_ARG(ctx, (x_hi == nullptr) == (x_lo == nullptr), PP_ERR_ARG, "pp_conv2d_nhwc_fwd_bf16x3: x_hi and x_lo go together");
+  PP_CHECK_ARG(ctx, d->cin % 32 == 0 && d->ld_x % 8 == 0, PP_ERR_SHAPE, "pp_conv2d_nhwc_fwd_bf16x3: cin %d must be a multiple of 32, ld_x of 8", d->cin);
+  PP_CHECK_ARG(ctx, !x_hi || (pp_is_aligned16(x_hi) && pp_is_aligned16(x_lo)), PP_ERR_ALIGN, "pp_conv2d_nhwc_fwd_bf16x3: plane alignment");
+  PP_CHECK_ARG(ctx, (!x || pp_is_aligned16(x)) && pp_is_aligned16(w_hi) && pp_is_aligned16(w_lo) && pp_is_aligned16(y), PP_ERR_ALIGN,
                "pp_conv2d_nhwc_fwd_bf16x3: tensors must be 16-byte aligned");
   PP_CHECK_ARG(ctx, !residual || (ld_res % 4 == 0 && ld_res >= ((d->cout + 3) & ~3) && pp_is_aligned16(residual)), PP_ERR_SHAPE,
                "pp_conv2d_nhwc_fwd_bf16x3: residual");
@@ -359,21 +412,23 @@ extern "C" int pp_conv2d_nhwc_fwd_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, con
   p.Cred = d->cin; p.Nout = d->cout; p.w_tap_rows = d->cin;
   p.kh = d->kh; p.kw = d->kw;
   p.mul = d->stride; p.tsign = 1; p.off_y = -d->pad_t; p.off_x = -d->pad_l; p.div = 1;
-  dispatch3(ctx, p, w_hi, w_lo, d->cout, d->cin / 8);
+  dispatch3(ctx, p, x_hi, x_lo, w_hi, w_lo, d->cout, d->cin / 8);
   PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_fwd_bf16x3");
   return PP_OK;
 }
 
-extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* dy, const void* w_hi, const void* w_lo,
-                                              const float* addend, int ld_add, const float* relu_src, int ld_rs, float* dx) {
+extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* dy, const void* dy_hi, const void* dy_lo,
+                                              const void* w_hi, const void* w_lo, const float* addend, int ld_add,
+                                              const float* relu_src, int ld_rs, float* dx) {
   PP_REQUIRE_CTX(ctx);
   int rc = check_desc(ctx, d, "pp_conv2d_nhwc_bwd_data_bf16x3");
   if (rc) return rc;
-  PP_CHECK_ARG(ctx, dy && w_hi && w_lo && dx, PP_ERR_ARG, "pp_conv2d_nhwc_bwd_data_bf16x3: null tensor");
+  PP_CHECK_ARG(ctx, (dy || (dy_hi && dy_lo)) && w_hi && w_lo && dx, PP_ERR_ARG, "pp_conv2d_nhwc_bwd_data_bf16x3: null tensor");
+  PP_CHECK_ARG(ctx, (dy_hi == nullptr) == (dy_lo == nullptr) && d->ld_y % 8 == 0, PP_ERR_ARG, "pp_conv2d_nhwc_bwd_data_bf16x3: planes / ld_y");
   const int cred = (d->cout + 31) / 32 * 32;
   PP_CHECK_ARG(ctx, d->cin % 16 == 0 && d->ld_y >= cred && d->ld_y % 4 == 0, PP_ERR_SHAPE,
                "pp_conv2d_nhwc_bwd_data_bf16x3: dy needs ld_y >= %d (cout rounded up to 32, zero padded)", cred);
-  PP_CHECK_ARG(ctx, pp_is_aligned16(dy) && pp_is_aligned16(w_hi) && pp_is_aligned16(w_lo) && pp_is_aligned16(dx), PP_ERR_ALIGN,
+  PP_CHECK_ARG(ctx, (!dy || pp_is_aligned16(dy)) && pp_is_aligned16(w_hi) && pp_is_aligned16(w_lo) && pp_is_aligned16(dx), PP_ERR_ALIGN,
                "pp_conv2d_nhwc_bwd_data_bf16x3: tensors must be 16-byte aligned");
   PP_CHECK_ARG(ctx, (!addend || (ld_add >= d->cin && ld_add % 4 == 0 && pp_is_aligned16(addend))) &&
                         (!relu_src || (ld_rs >= d->cin && ld_rs % 4 == 0 && pp_is_aligned16(relu_src))),
@@ -388,7 +443,7 @@ extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d
   p.Cred = cred; p.Nout = d->cin; p.w_tap_rows = d->cin;
   p.kh = d->kh; p.kw = d->kw;
   p.mul = 1; p.tsign = -1; p.off_y = d->pad_t; p.off_x = d->pad_l; p.div = d->stride;
-  dispatch3(ctx, p, w_hi, w_lo, d->cin, cred / 8);
+  dispatch3(ctx, p, dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8);
   PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_data_bf16x3");
   return PP_OK;
 }
@@ -435,10 +490,13 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned short* lds, int elem_of
   return *reinterpret_cast<bf16x8*>(&v);
 }
 
-template <int TM, int TN>
+// AP: x and dy come from pre-split bf16 planes (16-byte = 8-channel chunks, no conversion in the loop).
+template <int TM, int TN, bool AP>
 __global__ __launch_bounds__(256, (TM * TN == 4) ? 2 : 3) void wgrad3_kernel(const Wgrad3Params p, const float* __restrict__ g_src,
-                                                                            const float* __restrict__ g_dy, float* __restrict__ g_dw,
-                                                                            float* __restrict__ g_dbias) {
+                                                                            const float* __restrict__ g_dy,
+                                                                            const uint4* __restrict__ g_xhi, const uint4* __restrict__ g_xlo,
+                                                                            const uint4* __restrict__ g_dhi, const uint4* __restrict__ g_dlo,
+                                                                            float* __restrict__ g_dw, float* __restrict__ g_dbias) {
   constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32;
   constexpr int PA = BM + 32, PB = BN + 32;  // LDS pitches in bf16 elements (row + 64 bytes)
   __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BK * (PA + PB)];
@@ -487,7 +545,9 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 2 : 3) void wgrad3_kernel(con
   };
   decode(m_begin + prow);
 
+  constexpr int OA = (BM / 64 > 0) ? BM / 64 : 1, OB = (BN / 64 > 0) ? BN / 64 : 1;  // 8-channel chunks per thread (AP)
   float4 ra[QA], rb[QB];
+  uint4 pah[OA], pal[OA], pbh[OB], pbl[OB];
   float4 bsum[QB];
 #pragma unroll
   for (int j = 0; j < QB; ++j) bsum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -498,15 +558,33 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 2 : 3) void wgrad3_kernel(con
     const int sx = w.x * p.stride + tx - p.pad_l;
     const bool in_rng = w.m < m_end;
     const bool ok = in_rng && ((unsigned)sy < (unsigned)w.SH) && ((unsigned)sx < (unsigned)w.SW);
-    const float* src = g_src + (long long)(w.sb + w.n * w.SH * w.SW + sy * w.SW + sx) * p.ld_src + ci0;
+    const long long xrow = (long long)(w.sb + w.n * w.SH * w.SW + sy * w.SW + sx) * p.ld_src + ci0;
+    if (AP) {
 #pragma unroll
-    for (int j = 0; j < QA; ++j)
-      ra[j] = ok ? *reinterpret_cast<const float4*>(src + 4 * (q8 + 8 * j)) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* dyr = g_dy + (long long)w.m * p.ld_dy + n0;
+      for (int j = 0; j < OA; ++j) {
+        const long long o8 = (xrow >> 3) + q8 + 8 * j;
+        pah[j] = ok ? g_xhi[o8] : make_uint4(0u, 0u, 0u, 0u);
+        pal[j] = ok ? g_xlo[o8] : make_uint4(0u, 0u, 0u, 0u);
+      }
 #pragma unroll
-    for (int j = 0; j < QB; ++j) {
-      const int c = n0 + 4 * (q8 + 8 * j);
-      rb[j] = (in_rng && c < p.ld_dy) ? *reinterpret_cast<const float4*>(dyr + 4 * (q8 + 8 * j)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j < OB; ++j) {
+        const int c = n0 + 8 * (q8 + 8 * j);
+        const bool okb = in_rng && c < p.ld_dy;
+        const long long o8 = (((long long)w.m * p.ld_dy + n0) >> 3) + q8 + 8 * j;
+        pbh[j] = okb ? g_dhi[o8] : make_uint4(0u, 0u, 0u, 0u);
+        pbl[j] = okb ? g_dlo[o8] : make_uint4(0u, 0u, 0u, 0u);
+      }
+    } else {
+      const float* src = g_src + xrow;
+#pragma unroll
+      for (int j = 0; j < QA; ++j)
+        ra[j] = ok ? *reinterpret_cast<const float4*>(src + 4 * (q8 + 8 * j)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* dyr = g_dy + (long long)w.m * p.ld_dy + n0;
+#pragma unroll
+      for (int j = 0; j < QB; ++j) {
+        const int c = n0 + 4 * (q8 + 8 * j);
+        rb[j] = (in_rng && c < p.ld_dy) ? *reinterpret_cast<const float4*>(dyr + 4 * (q8 + 8 * j)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
     // advance this thread's pixel row by one step
     const int m2 = w.m + BK;
@@ -519,7 +597,44 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 2 : 3) void wgrad3_kernel(con
       while (w.y >= w.OH) { w.y -= w.OH; ++w.n; }
     }
   };
+  auto bf2f = [](unsigned int packed, float* lo_elem, float* hi_elem) {
+    *lo_elem = __uint_as_float(packed << 16);
+    *hi_elem = __uint_as_float(packed & 0xffff0000u);
+  };
   auto store_step = [&]() {
+    if (AP) {
+#pragma unroll
+      for (int j = 0; j < OA; ++j) {
+        const int off = prow * PA + 8 * (q8 + 8 * j);
+        if (8 * (q8 + 8 * j) < BM) {
+          *reinterpret_cast<uint4*>(Xhi + off) = pah[j];
+          *reinterpret_cast<uint4*>(Xlo + off) = pal[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < OB; ++j) {
+        const int off = prow * PB + 8 * (q8 + 8 * j);
+        if (8 * (q8 + 8 * j) < BN) {
+          *reinterpret_cast<uint4*>(Ghi + off) = pbh[j];
+          *reinterpret_cast<uint4*>(Glo + off) = pbl[j];
+          if (do_bias) {  // dy = hi + lo (2^-17): only the workgroups of the first k-tile pay for this
+            const unsigned int hw[4] = {pbh[j].x, pbh[j].y, pbh[j].z, pbh[j].w}, lw[4] = {pbl[j].x, pbl[j].y, pbl[j].z, pbl[j].w};
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float h0, h1, l0, l1;
+              bf2f(hw[e], &h0, &h1);
+              bf2f(lw[e], &l0, &l1);
+              v[2 * e] = h0 + l0;
+              v[2 * e + 1] = h1 + l1;
+            }
+            bsum[2 * j].x += v[0]; bsum[2 * j].y += v[1]; bsum[2 * j].z += v[2]; bsum[2 * j].w += v[3];
+            bsum[2 * j + 1].x += v[4]; bsum[2 * j + 1].y += v[5]; bsum[2 * j + 1].z += v[6]; bsum[2 * j + 1].w += v[7];
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < QA; ++j) {
       uint2 hi, lo;
@@ -609,8 +724,17 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 2 : 3) void wgrad3_kernel(con
     // 32 threads (one per pixel row of the step) hold partial sums of the same channel quad: reduce through LDS
     float* red = reinterpret_cast<float*>(smem);  // [32][BN] floats <= LDS size
     __syncthreads();
+    if (AP) {
 #pragma unroll
-    for (int j = 0; j < QB; ++j) *reinterpret_cast<float4*>(red + prow * BN + 4 * (q8 + 8 * j)) = bsum[j];
+      for (int j = 0; j < OB; ++j)
+        if (8 * (q8 + 8 * j) < BN) {
+          *reinterpret_cast<float4*>(red + prow * BN + 8 * (q8 + 8 * j)) = bsum[2 * j];
+          *reinterpret_cast<float4*>(red + prow * BN + 8 * (q8 + 8 * j) + 4) = bsum[2 * j + 1];
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < QB; ++j) *reinterpret_cast<float4*>(red + prow * BN + 4 * (q8 + 8 * j)) = bsum[j];
+    }
     __syncthreads();
     if (tid < BN) {
       float s = 0.f;
@@ -622,7 +746,8 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 2 : 3) void wgrad3_kernel(con
 }
 
 template <int TM, int TN>
-static void launch_wgrad3(pp_ctx* ctx, Wgrad3Params& p, const float* x, const float* dy, float* dw, float* dbias) {
+static void launch_wgrad3(pp_ctx* ctx, Wgrad3Params& p, const float* x, const float* dy, const void* xhi, const void* xlo, const void* dhi,
+                          const void* dlo, float* dw, float* dbias) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   p.k_tiles_per_tap = p.Cin / BM;
   p.n_tiles_k = p.kh * p.kw * p.k_tiles_per_tap;
@@ -650,18 +775,27 @@ static void launch_wgrad3(pp_ctx* ctx, Wgrad3Params& p, const float* x, const fl
   splits = (p.M + rps - 1) / rps;
   p.splits = splits;
   p.rows_per_split = rps;
-  hipLaunchKernelGGL((wgrad3_kernel<TM, TN>), dim3((unsigned)(tiles * splits)), dim3(256), 0, ctx->stream, p, x, dy, dw, dbias);
+  if (xhi)
+    hipLaunchKernelGGL((wgrad3_kernel<TM, TN, true>), dim3((unsigned)(tiles * splits)), dim3(256), 0, ctx->stream, p, x, dy, (const uint4*)xhi,
+                       (const uint4*)xlo, (const uint4*)dhi, (const uint4*)dlo, dw, dbias);
+  else
+    hipLaunchKernelGGL((wgrad3_kernel<TM, TN, false>), dim3((unsigned)(tiles * splits)), dim3(256), 0, ctx->stream, p, x, dy,
+                       (const uint4*)nullptr, (const uint4*)nullptr, (const uint4*)nullptr, (const uint4*)nullptr, dw, dbias);
 }
 
-extern "C" int pp_conv2d_nhwc_bwd_weight_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const float* dy, float* dw,
-                                                float* dbias) {
+extern "C" int pp_conv2d_nhwc_bwd_weight_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const float* dy, const void* x_hi,
+                                                const void* x_lo, const void* dy_hi, const void* dy_lo, float* dw, float* dbias) {
   PP_REQUIRE_CTX(ctx);
   int rc = check_desc(ctx, d, "pp_conv2d_nhwc_bwd_weight_bf16x3");
   if (rc) return rc;
-  PP_CHECK_ARG(ctx, x && dy && dw, PP_ERR_ARG, "pp_conv2d_nhwc_bwd_weight_bf16x3: null tensor");
+  const bool planes = x_hi && x_lo && dy_hi && dy_lo;
+  PP_CHECK_ARG(ctx, ((x && dy) || planes) && dw, PP_ERR_ARG, "pp_conv2d_nhwc_bwd_weight_bf16x3: null tensor");
+  PP_CHECK_ARG(ctx, planes || !(x_hi || x_lo || dy_hi || dy_lo), PP_ERR_ARG, "pp_conv2d_nhwc_bwd_weight_bf16x3: all four planes or none");
+  PP_CHECK_ARG(ctx, !planes || (d->ld_x % 8 == 0 && d->ld_y % 8 == 0), PP_ERR_SHAPE, "pp_conv2d_nhwc_bwd_weight_bf16x3: planes need ld % 8 == 0");
   PP_CHECK_ARG(ctx, d->cin % 64 == 0, PP_ERR_SHAPE, "pp_conv2d_nhwc_bwd_weight_bf16x3: cin %d must be a multiple of 64", d->cin);
   PP_CHECK_ARG(ctx, d->ld_y % 4 == 0 && d->ld_x % 4 == 0, PP_ERR_SHAPE, "pp_conv2d_nhwc_bwd_weight_bf16x3: leading dims must be multiples of 4");
-  PP_CHECK_ARG(ctx, pp_is_aligned16(x) && pp_is_aligned16(dy), PP_ERR_ALIGN, "pp_conv2d_nhwc_bwd_weight_bf16x3: tensors must be 16-byte aligned");
+  PP_CHECK_ARG(ctx, (!x || pp_is_aligned16(x)) && (!dy || pp_is_aligned16(dy)), PP_ERR_ALIGN,
+               "pp_conv2d_nhwc_bwd_weight_bf16x3: tensors must be 16-byte aligned");
   Wgrad3Params p;
   memset(&p, 0, sizeof(p));
   p.ld_src = d->ld_x; p.ld_dy = d->ld_y; p.ld_w = d->ld_w;
@@ -671,10 +805,10 @@ extern "C" int pp_conv2d_nhwc_bwd_weight_bf16x3(pp_ctx* ctx, const pp_conv_desc*
   p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
   const bool big_k = (d->cin % 128 == 0);
   const bool big_n = ((d->cout + 127) / 128 * 128) <= ((d->cout + 63) / 64 * 64);
-  if (big_k && big_n) launch_wgrad3<2, 2>(ctx, p, x, dy, dw, dbias);
-  else if (big_k) launch_wgrad3<2, 1>(ctx, p, x, dy, dw, dbias);
-  else if (big_n) launch_wgrad3<1, 2>(ctx, p, x, dy, dw, dbias);
-  else launch_wgrad3<1, 1>(ctx, p, x, dy, dw, dbias);
+  if (big_k && big_n) launch_wgrad3<2, 2>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias);
+  else if (big_k) launch_wgrad3<2, 1>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias);
+  else if (big_n) launch_wgrad3<1, 2>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias);
+  else launch_wgrad3<1, 1>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias);
   PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_weight_bf16x3");
   return PP_OK;
 }

@@ -157,6 +157,16 @@ def test_conv_fwd_bwd(ctx, case):
     assert np.all(dw.cpu().numpy()[:, cout:] == 0)
     db_ref = sum(g.reshape(-1, cout).sum(0) for g in gys).numpy()
     assert rel_err(db.cpu().numpy()[:cout], db_ref) < 5e-5
+    # operands from pre-split planes
+    xd, gd = _cat_rows(xs), _cat_rows(gys, ld_y)
+    xh, xl = torch.zeros_like(xd, dtype=torch.int16), torch.zeros_like(xd, dtype=torch.int16)
+    gh, gl = torch.zeros_like(gd, dtype=torch.int16), torch.zeros_like(gd, dtype=torch.int16)
+    ops.split_planes3(ctx, xd, xh, xl)
+    ops.split_planes3(ctx, gd, gh, gl)
+    dw2 = torch.zeros_like(dw); db2 = torch.zeros_like(db)
+    ops.conv_bwd_weight3(ctx, d, None, None, dw2, db2, x_planes=(xh, xl), dy_planes=(gh, gl))
+    assert rel_err(dw2.cpu().numpy()[:, :cout], gw_ref.reshape(-1, cout).numpy()) < 1e-4
+    assert rel_err(db2.cpu().numpy()[:cout], db_ref) < 5e-5
 
 
 def test_stem_7x7_rgb(ctx):
@@ -262,6 +272,13 @@ def test_conv_bf16x3_fwd_bwd_data(ctx, case):
     want = torch.cat([torch.relu(r + q).reshape(-1, cout) for r, q in zip(ref, res)], dim=0).numpy()
     e = rel_err(y.cpu().numpy()[:, :cout], want)
     assert e < 1e-4, e
+    # same launch with the gathered operand pre-split into (hi, lo) planes: bit-identical result
+    xh, xl = torch.zeros_like(x, dtype=torch.int16), torch.zeros_like(x, dtype=torch.int16)
+    ops.split_planes3(ctx, x, xh, xl)
+    assert rel_err((xh.view(torch.bfloat16).float() + xl.view(torch.bfloat16).float()).cpu().numpy(), x.cpu().numpy()) < 2e-5
+    y2 = torch.full_like(y, float("nan"))
+    ops.conv_fwd3(ctx, d, None, fh, fl, bd.cuda(), _cat_rows(res, ld_y), True, y2, x_planes=(xh, xl))
+    assert torch.equal(y2[:, :cout], y[:, :cout])
     # bwd-data against float64 autograd
     xg = [t.clone().requires_grad_(True) for t in xs]
     wt = torch.as_tensor(w, dtype=torch.float64)
@@ -284,6 +301,11 @@ def test_conv_bf16x3_fwd_bwd_data(ctx, case):
     want = torch.cat([((g + a) * (r > 0)).reshape(-1, cin) for g, a, r in zip(gx_ref, addend, rsrc)], dim=0).numpy()
     e = rel_err(dx.cpu().numpy(), want)
     assert e < 1e-4, e
+    gh, gl = torch.zeros_like(gy, dtype=torch.int16), torch.zeros_like(gy, dtype=torch.int16)
+    ops.split_planes3(ctx, gy, gh, gl)
+    dx2 = torch.full_like(dx, float("nan"))
+    ops.conv_bwd_data3(ctx, d, None, dh, dl, _cat_rows(addend), _cat_rows(rsrc), dx2, dy_planes=(gh, gl))
+    assert torch.equal(dx2, dx)
 
 
 WG3_CASES = [c for c in CASES if c[3] % 64 == 0]
@@ -324,3 +346,13 @@ def test_conv_bf16x3_bwd_weight(ctx, case):
     assert np.all(dw.cpu().numpy()[:, cout:] == 0)
     db_ref = sum(g.reshape(-1, cout).sum(0) for g in gys).numpy()
     assert rel_err(db.cpu().numpy()[:cout], db_ref) < 5e-5
+    # operands from pre-split planes
+    xd, gd = _cat_rows(xs), _cat_rows(gys, ld_y)
+    xh, xl = torch.zeros_like(xd, dtype=torch.int16), torch.zeros_like(xd, dtype=torch.int16)
+    gh, gl = torch.zeros_like(gd, dtype=torch.int16), torch.zeros_like(gd, dtype=torch.int16)
+    ops.split_planes3(ctx, xd, xh, xl)
+    ops.split_planes3(ctx, gd, gh, gl)
+    dw2 = torch.zeros_like(dw); db2 = torch.zeros_like(db)
+    ops.conv_bwd_weight3(ctx, d, None, None, dw2, db2, x_planes=(xh, xl), dy_planes=(gh, gl))
+    assert rel_err(dw2.cpu().numpy()[:, :cout], gw_ref.reshape(-1, cout).numpy()) < 1e-4
+    assert rel_err(db2.cpu().numpy()[:cout], db_ref) < 5e-5

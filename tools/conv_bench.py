@@ -67,7 +67,15 @@ def main():
             fh, fl = torch.zeros((taps, cout, cin), **i16), torch.zeros((taps, cout, cin), **i16)
             dh, dl = torch.zeros((taps, cin, cout), **i16), torch.zeros((taps, cin, cout), **i16)
             ops.conv_split_weights3(ctx, d, w, fh, fl, dh, dl)
-        fns = {"fwd3": lambda: ops.conv_fwd3(ctx, d, x, fh, fl, bias, None, True, y),
+        xh, xl = torch.zeros_like(x, dtype=torch.int16), torch.zeros_like(x, dtype=torch.int16)
+        gh, gl = torch.zeros_like(dy, dtype=torch.int16), torch.zeros_like(dy, dtype=torch.int16)
+        ops.split_planes3(ctx, x, xh, xl)
+        ops.split_planes3(ctx, dy, gh, gl)
+        fns = {"fwd3p": lambda: ops.conv_fwd3(ctx, d, None, fh, fl, bias, None, True, y, x_planes=(xh, xl)),
+               "dgrad3p": lambda: ops.conv_bwd_data3(ctx, d, None, dh, dl, None, x, dx, dy_planes=(gh, gl)),
+               "wgrad3p": lambda: ops.conv_bwd_weight3(ctx, d, None, None, dw, db, x_planes=(xh, xl), dy_planes=(gh, gl)),
+               "splitx": lambda: ops.split_planes3(ctx, x, xh, xl),
+               "fwd3": lambda: ops.conv_fwd3(ctx, d, x, fh, fl, bias, None, True, y),
                "dgrad3": lambda: ops.conv_bwd_data3(ctx, d, dy, dh, dl, None, x, dx),
                "wgrad3": lambda: ops.conv_bwd_weight3(ctx, d, x, dy, dw, db),
                "split3": lambda: ops.conv_split_weights3(ctx, d, w, fh, fl, dh, dl),
