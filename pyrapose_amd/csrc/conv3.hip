@@ -32,7 +32,7 @@ __device__ __forceinline__ void split8(const float4& lo4, const float4& hi4, uin
 // AP: the gathered operand comes from pre-split bf16 (hi, lo) planes (pp_split_planes_bf16x3, same [rows][ld]
 // geometry as the f32 tensor) instead of being split from f32 while staging: no conversion VALU in the loop.
 template <int TM, int TN, bool AP>
-__global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3_kernel(
+__global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4)) void igemm3_kernel(
     const IgemmParams p, const float* __restrict__ g_src, const uint4* __restrict__ g_ahi, const uint4* __restrict__ g_alo,
     const uint4* __restrict__ g_whi, const uint4* __restrict__ g_wlo,
     const float* __restrict__ g_bias, const float* __restrict__ g_addend, const float* __restrict__ g_mask,
@@ -152,8 +152,9 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3_kernel(
   store_step();
   __syncthreads();
 
-  // (a double-buffered LDS variant -- one barrier per step, 64 KB per workgroup -- measured 15-20 % SLOWER:
-  //  the occupancy drop from 3 to 2 workgroups per CU costs more than the second barrier)
+  // Measured alternatives that were NOT kept: double-buffered LDS with one barrier per step (64 KB per workgroup,
+  // occupancy 3 -> 2: 15-20 % slower); weights streamed by LDS-DMA (global_load_lds_dwordx4, swizzled source,
+  // double-buffered B stage): correct but 2-5 % slower -- the DMA issue cost replaces the ds_write cost.
   for (int step = 0; step < n_steps; ++step) {
     const bool more = step + 1 < n_steps;
     if (more) {
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3_kernel(
   }
 
   // ---- epilogue through LDS (see conv.hip): blocked sub-tiles here, so staged row = (a - a0) * 32 + i ----
-  constexpr int SUB = (TM * BN > 256 * 1) ? 1 : TM;  // 32*SUB rows x BN floats must fit the 16*SMEM_U4-byte buffer
+  constexpr int SUB = (TM == 4) ? 2 : ((TM * BN > 256 * 1) ? 1 : TM);  // 32*SUB rows x BN floats must fit the LDS buffer
   constexpr int ROWS = 32 * SUB;
   constexpr int C4 = BN / 4;
   constexpr int RPI = 256 / C4;
@@ -355,12 +356,14 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
 }
 
 static void pick_tile3(const pp_ctx* ctx, int M, int Nout, int* tm, int* tn) {
-  static const int cand[4][2] = {{2, 2}, {1, 2}, {2, 1}, {1, 1}};
-  static const double eff[4] = {1.0, 0.9, 0.9, 0.8};
-  static const int slots[4] = {3, 4, 4, 4};
+  // measured in-flight rates relative to 128x128 (tools/conv_bench.py): the LDS store path (ds_write_b128 of the
+  // staged tiles) costs ~30 % of the loop, so the tile with the fewest staged bytes per MFMA wins when it fills the chip
+  static const int cand[5][2] = {{4, 2}, {2, 2}, {1, 2}, {2, 1}, {1, 1}};
+  static const double eff[5] = {1.1, 1.0, 0.9, 0.9, 0.8};
+  static const int slots[5] = {2, 3, 4, 4, 4};
   const int cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
   double best = 1e300;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 5; ++i) {
     const int bm = 64 * cand[i][0], bn = 64 * cand[i][1];
     const long long blocks = (long long)((M + bm - 1) / bm) * ((Nout + bn - 1) / bn);
     const double t = est_rounds(blocks, slots[i], cus) * cand[i][0] * cand[i][1] / eff[i];
@@ -381,7 +384,8 @@ static void dispatch3(pp_ctx* ctx, IgemmParams& p, const void* ahi, const void* 
                       int w_ld8) {
   int tm, tn;
   pick_tile3(ctx, p.M, p.Nout, &tm, &tn);
-  if (tm == 2 && tn == 2) launch_igemm3<2, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8);
+  if (tm == 4) launch_igemm3<4, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8);
+  else if (tm == 2 && tn == 2) launch_igemm3<2, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8);
   else if (tm == 1 && tn == 2) launch_igemm3<1, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8);
   else if (tm == 2 && tn == 1) launch_igemm3<2, 1>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8);
   else launch_igemm3<1, 1>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8);
