@@ -86,8 +86,15 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # PP_DIST_BACKEND=gloo + fewer GPUs than ranks is a rehearsal mode (several ranks share a card); the driver's
+        # scaling runs use the default: RCCL ("nccl"), one rank per GPU.
+        backend = os.environ.get("PP_DIST_BACKEND", "nccl")
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
         local_rank = 0
