@@ -106,11 +106,14 @@ int pp_conv_split_weights_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float
 int pp_split_planes_bf16x3(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo);
 int pp_conv2d_nhwc_fwd_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const void* x_hi, const void* x_lo,
                               const void* w_fwd_hi, const void* w_fwd_lo, const float* bias, const float* residual,
-                              int ld_res, int relu, float* y);
+                              int ld_res, int relu, float* y, void* y_hi, void* y_lo);
+/* y_hi / y_lo (may be NULL): the epilogue also writes the output pre-split, so that the consumer convs skip the split.
+ * With planes given, y (fwd) / dx (bwd_data) may be NULL: the output then exists only as planes. */
 /* dy rows need ld_y >= cout rounded up to 32 with zero padding. */
 int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* dy, const void* dy_hi,
                                    const void* dy_lo, const void* w_dgrad_hi, const void* w_dgrad_lo,
-                                   const float* addend, int ld_add, const float* relu_src, int ld_rs, float* dx);
+                                   const float* addend, int ld_add, const float* relu_src, int ld_rs, float* dx,
+                                   void* dx_hi, void* dx_lo);
 /* dw += x^T (*) dy; operands either f32 (split on the fly) or all four planes; same contract as
  * pp_conv2d_nhwc_bwd_weight, cin % 64 == 0. */
 int pp_conv2d_nhwc_bwd_weight_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const float* dy,

@@ -31,12 +31,111 @@ __device__ __forceinline__ void split8(const float4& lo4, const float4& hi4, uin
 
 // AP: the gathered operand comes from pre-split bf16 (hi, lo) planes (pp_split_planes_bf16x3, same [rows][ld]
 // geometry as the f32 tensor) instead of being split from f32 while staging: no conversion VALU in the loop.
-template <int TM, int TN, bool AP>
+__device__ __forceinline__ void split4(const float4& v4, uint2* out_hi, uint2* out_lo) {
+  const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  bf16x4 h, l;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const __bf16 hh = (__bf16)v[j];
+    h[j] = hh;
+    l[j] = (__bf16)(v[j] - (float)hh);
+  }
+  *out_hi = *reinterpret_cast<uint2*>(&h);
+  *out_lo = *reinterpret_cast<uint2*>(&l);
+}
+
+// ---- epilogue through LDS (see conv.hip), shared by both main loops ----
+template <int TM, int TN, bool OP, int GOP = 1>
+__device__ __forceinline__ void epilogue3(const IgemmParams& p, floatx16 (&acc)[TM][TN], uint4* smem, int m0, int n0, int tid, int wm,
+                                          int wn, int il, int h, const float* __restrict__ g_bias,
+                                          const float* __restrict__ g_addend, const float* __restrict__ g_mask,
+                                          float* __restrict__ g_out, uint2* __restrict__ g_ohi, uint2* __restrict__ g_olo) {
+  constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, NO = BK / 8;
+  constexpr int SMEM_U4 = 2 * NO * (BM + BN);
+  // blocked sub-tiles here, so staged row = (a - a0) * 32 + i
+  constexpr int SUB = (TM == 4) ? 2 : ((TM * BN > 256 * 1) ? 1 : TM);  // 32*SUB rows x BN floats must fit the LDS buffer
+  constexpr int ROWS = 32 * SUB;
+  constexpr int C4 = BN / 4;
+  constexpr int RPI = 256 / C4;
+  constexpr int SWEEPS = ROWS / RPI;
+  static_assert(ROWS * BN * 4 <= SMEM_U4 * 16, "epilogue staging does not fit");
+  float* stage = reinterpret_cast<float*>(smem);
+  const int e_c4 = tid % C4, e_r = tid / C4;
+  const int co = n0 + 4 * e_c4;
+  const bool col_ok = co < ((p.Nout + 3) & ~3);
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g_bias && col_ok) bias4 = *reinterpret_cast<const float4*>(g_bias + co);
+  const int m_last = p.M - 1;
+#pragma unroll
+  for (int hm = 0; hm < 2; ++hm) {
+#pragma unroll
+    for (int a0 = 0; a0 < TM; a0 += SUB) {
+      __syncthreads();
+      if (wm == hm) {
+#pragma unroll
+        for (int as = 0; as < SUB; ++as)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = as * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+            for (int b = 0; b < TN; ++b) stage[row * BN + wn * 32 * TN + b * 32 + il] = acc[a0 + as][b][r];
+          }
+      }
+      __syncthreads();
+      if (col_ok) {
+        constexpr int G = OP ? (SWEEPS < GOP ? SWEEPS : GOP) : (SWEEPS < 4 ? SWEEPS : 4);  // rows in flight per thread
+        const int base_row = m0 + hm * 32 * TM + a0 * 32;
+        auto sweep = [&](auto has_add, auto has_mask) {
+#pragma unroll
+          for (int s0 = 0; s0 < SWEEPS; s0 += G) {
+            float4 ad[G], mk[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+              const int m = min(base_row + e_r + RPI * (s0 + g), m_last);
+              if (has_add) ad[g] = *reinterpret_cast<const float4*>(g_addend + (long long)m * p.ld_add + co);
+              if (has_mask) mk[g] = *reinterpret_cast<const float4*>(g_mask + (long long)m * p.ld_mask + co);
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+              const int row = e_r + RPI * (s0 + g);
+              const int m = base_row + row;
+              float4 v = *reinterpret_cast<const float4*>(stage + row * BN + 4 * e_c4);
+              v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+              if (has_add) { v.x += ad[g].x; v.y += ad[g].y; v.z += ad[g].z; v.w += ad[g].w; }
+              if (has_mask) {
+                v.x = mk[g].x > 0.f ? v.x : 0.f; v.y = mk[g].y > 0.f ? v.y : 0.f;
+                v.z = mk[g].z > 0.f ? v.z : 0.f; v.w = mk[g].w > 0.f ? v.w : 0.f;
+              }
+              if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+              if (m <= m_last) {
+                if (!OP || g_out != nullptr) *reinterpret_cast<float4*>(g_out + (long long)m * p.ld_out + co) = v;
+                if (OP) {  // the consumer convs read their operand pre-split: split once here instead of per tile
+                  uint2 oh, ol;
+                  split4(v, &oh, &ol);
+                  const long long o4 = ((long long)m * p.ld_out + co) >> 2;
+                  g_ohi[o4] = oh;
+                  g_olo[o4] = ol;
+                }
+              }
+            }
+          }
+        };
+        if (g_addend != nullptr && g_mask != nullptr) sweep(std::true_type{}, std::true_type{});
+        else if (g_addend != nullptr) sweep(std::true_type{}, std::false_type{});
+        else if (g_mask != nullptr) sweep(std::false_type{}, std::true_type{});
+        else sweep(std::false_type{}, std::false_type{});
+      }
+    }
+  }
+}
+
+template <int TM, int TN, bool AP, bool OP>
 __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4)) void igemm3_kernel(
     const IgemmParams p, const float* __restrict__ g_src, const uint4* __restrict__ g_ahi, const uint4* __restrict__ g_alo,
     const uint4* __restrict__ g_whi, const uint4* __restrict__ g_wlo,
     const float* __restrict__ g_bias, const float* __restrict__ g_addend, const float* __restrict__ g_mask,
-    float* __restrict__ g_out, int w_rows, int w_ld8) {
+    float* __restrict__ g_out, uint2* __restrict__ g_ohi, uint2* __restrict__ g_olo, int w_rows, int w_ld8) {
   constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, NO = BK / 8;
   constexpr int SMEM_U4 = 2 * NO * (BM + BN);
   __shared__ __attribute__((aligned(16))) uint4 smem[SMEM_U4];
@@ -197,72 +296,200 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
     }
   }
 
-  // ---- epilogue through LDS (see conv.hip): blocked sub-tiles here, so staged row = (a - a0) * 32 + i ----
-  constexpr int SUB = (TM == 4) ? 2 : ((TM * BN > 256 * 1) ? 1 : TM);  // 32*SUB rows x BN floats must fit the LDS buffer
-  constexpr int ROWS = 32 * SUB;
-  constexpr int C4 = BN / 4;
-  constexpr int RPI = 256 / C4;
-  constexpr int SWEEPS = ROWS / RPI;
-  static_assert(ROWS * BN * 4 <= SMEM_U4 * 16, "epilogue staging does not fit");
-  float* stage = reinterpret_cast<float*>(smem);
-  const int e_c4 = tid % C4, e_r = tid / C4;
-  const int co = n0 + 4 * e_c4;
-  const bool col_ok = co < ((p.Nout + 3) & ~3);
-  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (g_bias && col_ok) bias4 = *reinterpret_cast<const float4*>(g_bias + co);
-  const int m_last = p.M - 1;
+  epilogue3<TM, TN, OP>(p, acc, smem, m0, n0, tid, wm, wn, il, h, g_bias, g_addend, g_mask, g_out, g_ohi, g_olo);
+}
+
+// ---- igemm3f: the same tile and LDS image with a branch-free, 32-bit-addressed main loop ----
+// For gathers that are linear in the tap (div == 1: forward at any stride, bwd-data at stride 1).  Per staged row the
+// kernel keeps a byte offset of tap (0,0), the row pitch of its level and a validity bit per tap; every step's
+// operand addresses are then 4 VALU per row (mad + add + bit test + select) and the loads are raw buffer loads,
+// whose out-of-range offsets return zeros -- padding taps and rows past M need no branch, so the whole k-loop body
+// is ONE basic block that the scheduler can interleave under the MFMAs.  Buffers must stay below 2 GiB
+// (host-checked; larger tensors take igemm3_kernel).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define PP_BUF_OOB ((int)0x80000000)
+
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// Measured and NOT kept: the same loop on v_mfma_f32_16x16x32_bf16 (48 instead of 24 MFMAs per step, lane = (row, octet)
+// staging map, un-rotated image): bit-identical results, 20 % slower on every head shape (255-295 vs 325-355 TFLOP/s).
+template <int TM, int TN, bool AP, bool OP>
+__global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4)) void igemm3f_kernel(
+    const IgemmParams p, const void* __restrict__ g_a0, const void* __restrict__ g_a1, unsigned a_bytes,
+    const void* __restrict__ g_whi, const void* __restrict__ g_wlo, unsigned w_bytes,
+    const float* __restrict__ g_bias, const float* __restrict__ g_addend, const float* __restrict__ g_mask,
+    float* __restrict__ g_out, uint2* __restrict__ g_ohi, uint2* __restrict__ g_olo, int w_rows, int w_ld8) {
+  constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, NO = BK / 8;
+  constexpr int SMEM_U4 = 2 * NO * (BM + BN);
+  constexpr int ES = AP ? 2 : 4;  // bytes per gathered element
+  __shared__ __attribute__((aligned(16))) uint4 smem[SMEM_U4];
+  uint4* Ahi = smem;
+  uint4* Alo = Ahi + NO * BM;
+  uint4* Bhi = Alo + NO * BM;
+  uint4* Blo = Bhi + NO * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lb = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int tile_n = lb % p.n_tiles_n, tile_m = lb / p.n_tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int oct = tid & 3, r0 = tid >> 2;
+  const int n_taps = p.kh * p.kw;
+  const int n_steps = n_taps * (p.Cred / BK);
+
+  const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_a0), 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(AP ? g_a1 : g_a0), 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_whi), 0, w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_wlo), 0, w_bytes, 0x00020000);
+
+  // per staged row: byte offset at tap (0,0), pitch of one tap row, validity bit per tap
+  int a_base[TM], a_pitch[TM];
+  unsigned a_valid[TM];
 #pragma unroll
-  for (int hm = 0; hm < 2; ++hm) {
-#pragma unroll
-    for (int a0 = 0; a0 < TM; a0 += SUB) {
-      __syncthreads();
-      if (wm == hm) {
-#pragma unroll
-        for (int as = 0; as < SUB; ++as)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = as * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-#pragma unroll
-            for (int b = 0; b < TN; ++b) stage[row * BN + wn * 32 * TN + b * 32 + il] = acc[a0 + as][b][r];
-          }
+  for (int i = 0; i < TM; ++i) {
+    const RowPos r = decode_row(p, m0 + r0 + 64 * i);
+    a_base[i] = ((r.rowbase + r.ybase * r.SW + r.xbase) * p.ld_src + 8 * oct) * ES;
+    a_pitch[i] = p.tsign * r.SW * p.ld_src * ES;
+    unsigned v = 0;
+    int t = 0;
+    for (int ty = 0; ty < p.kh; ++ty)
+      for (int tx = 0; tx < p.kw; ++tx, ++t) {
+        const int sy = r.ybase + ty * p.tsign, sx = r.xbase + tx * p.tsign;
+        if (r.ok && (unsigned)sy < (unsigned)r.SH && (unsigned)sx < (unsigned)r.SW) v |= 1u << t;
       }
-      __syncthreads();
-      if (col_ok) {
-        constexpr int G = SWEEPS < 4 ? SWEEPS : 4;
-        const int base_row = m0 + hm * 32 * TM + a0 * 32;
-        auto sweep = [&](auto has_add, auto has_mask) {
+    a_valid[i] = v;
+  }
+  const int x_pitch = p.tsign * p.ld_src * ES;
+  int b_base[TN];
 #pragma unroll
-          for (int s0 = 0; s0 < SWEEPS; s0 += G) {
-            float4 ad[G], mk[G];
+  for (int i = 0; i < TN; ++i) {
+    const int n = n0 + r0 + 64 * i;
+    b_base[i] = n < w_rows ? (n * w_ld8 + oct) * 16 : PP_BUF_OOB;
+  }
+  const int b_tap = w_rows * w_ld8 * 16;
+
+  float4 ra[TM][2];
+  uint4 rah[TM], ral[TM];
+  uint4 rbh[TN], rbl[TN];
+  int tap = 0, ty = 0, tx = 0, red0 = 0;
+
+  auto load_step = [&]() {
+    const int a_uni = tx * x_pitch + red0 * ES;
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-              const int m = min(base_row + e_r + RPI * (s0 + g), m_last);
-              if (has_add) ad[g] = *reinterpret_cast<const float4*>(g_addend + (long long)m * p.ld_add + co);
-              if (has_mask) mk[g] = *reinterpret_cast<const float4*>(g_mask + (long long)m * p.ld_mask + co);
-            }
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-              const int row = e_r + RPI * (s0 + g);
-              const int m = base_row + row;
-              float4 v = *reinterpret_cast<const float4*>(stage + row * BN + 4 * e_c4);
-              v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-              if (has_add) { v.x += ad[g].x; v.y += ad[g].y; v.z += ad[g].z; v.w += ad[g].w; }
-              if (has_mask) {
-                v.x = mk[g].x > 0.f ? v.x : 0.f; v.y = mk[g].y > 0.f ? v.y : 0.f;
-                v.z = mk[g].z > 0.f ? v.z : 0.f; v.w = mk[g].w > 0.f ? v.w : 0.f;
-              }
-              if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-              if (m <= m_last) *reinterpret_cast<float4*>(g_out + (long long)m * p.ld_out + co) = v;
-            }
-          }
-        };
-        if (g_addend != nullptr && g_mask != nullptr) sweep(std::true_type{}, std::true_type{});
-        else if (g_addend != nullptr) sweep(std::true_type{}, std::false_type{});
-        else if (g_mask != nullptr) sweep(std::false_type{}, std::true_type{});
-        else sweep(std::false_type{}, std::false_type{});
+    for (int i = 0; i < TM; ++i) {
+      int vo = a_base[i] + __mul24(ty, a_pitch[i]) + a_uni;
+      vo = ((a_valid[i] >> tap) & 1u) ? vo : PP_BUF_OOB;
+      if (AP) {
+        rah[i] = buf_load16(rs_a0, vo, 0);
+        ral[i] = buf_load16(rs_a1, vo, 0);
+      } else {
+        const uint4 q0 = buf_load16(rs_a0, vo, 0), q1 = buf_load16(rs_a0, vo + 16, 0);
+        ra[i][0] = *reinterpret_cast<const float4*>(&q0);
+        ra[i][1] = *reinterpret_cast<const float4*>(&q1);
       }
     }
+    const int b_uni = tap * b_tap + (red0 >> 3) * 16;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      rbh[i] = buf_load16(rs_wh, b_base[i], b_uni);
+      rbl[i] = buf_load16(rs_wl, b_base[i], b_uni);
+    }
+  };
+  auto advance = [&](bool more) {  // uniform, branch-free; past the last step it rewinds to step 0 (a harmless re-load)
+    red0 += BK;
+    const bool wrap = red0 >= p.Cred;
+    red0 = wrap ? 0 : red0;
+    tap += wrap ? 1 : 0;
+    tx += wrap ? 1 : 0;
+    const bool wx = tx == p.kw;
+    tx = wx ? 0 : tx;
+    ty += wx ? 1 : 0;
+    red0 = more ? red0 : 0;
+    tap = more ? tap : 0;
+    tx = more ? tx : 0;
+    ty = more ? ty : 0;
+  };
+  auto split_step = [&]() {
+    if (!AP) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) split8(ra[i][0], ra[i][1], &rah[i], &ral[i]);
+    }
+  };
+  auto store_step = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int slot = oct * BM + ((r0 + 64 * i + 2 * oct) & (BM - 1));
+      Ahi[slot] = rah[i];
+      Alo[slot] = ral[i];
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int slot = oct * BN + ((r0 + 64 * i + 2 * oct) & (BN - 1));
+      Bhi[slot] = rbh[i];
+      Blo[slot] = rbl[i];
+    }
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int il = lane & 31, h = lane >> 5;
+
+  load_step();
+  split_step();
+  store_step();
+  __syncthreads();
+
+  for (int step = 0; step < n_steps; ++step) {
+    advance(step + 1 < n_steps);
+    load_step();  // in flight under the MFMAs below
+    // (left alone the scheduler sinks the loads below the MFMAs, or pulls the conversion of the loaded tile -- and
+    // with it the wait for the loads -- up to the first MFMA: pin loads | first half of the MFMAs | rest + conversion)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      const int o = 2 * s + h;
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const int slot = o * BM + ((wm * 32 * TM + a * 32 + il + 2 * o) & (BM - 1));
+        uint4 t = Ahi[slot];
+        ah[a] = *reinterpret_cast<bf16x8*>(&t);
+        t = Alo[slot];
+        al[a] = *reinterpret_cast<bf16x8*>(&t);
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int slot = o * BN + ((wn * 32 * TN + b * 32 + il + 2 * o) & (BN - 1));
+        uint4 t = Bhi[slot];
+        bh[b] = *reinterpret_cast<bf16x8*>(&t);
+        t = Blo[slot];
+        bl[b] = *reinterpret_cast<bf16x8*>(&t);
+      }
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+        }
+      if (s == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    split_step();     // conversion VALU issues while this wave's MFMAs drain
+    __syncthreads();  // every wave has read this step's tiles
+    store_step();
+    __syncthreads();
   }
+  epilogue3<TM, TN, OP, 4>(p, acc, smem, m0, n0, tid, wm, wn, il, h, g_bias, g_addend, g_mask, g_out, g_ohi, g_olo);
 }
 
 // ---- activation / gradient split: f32 [rows][ld] -> bf16 hi/lo planes with the same geometry ----
@@ -342,17 +569,34 @@ extern "C" int pp_conv_split_weights_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, 
 
 template <int TM, int TN>
 static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const void* alo, const void* whi, const void* wlo, int w_rows,
-                          int w_ld8) {
+                          int w_ld8, void* ohi, void* olo) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   p.n_tiles_n = (p.Nout + BN - 1) / BN;
   const int n_tiles_m = (p.M + BM - 1) / BM;
   const dim3 grid((unsigned)(n_tiles_m * p.n_tiles_n));
-  if (ahi)
-    hipLaunchKernelGGL((igemm3_kernel<TM, TN, true>), grid, dim3(256), 0, st, p, p.src, (const uint4*)ahi, (const uint4*)alo,
-                       (const uint4*)whi, (const uint4*)wlo, p.bias, p.addend, p.mask_src, p.out, w_rows, w_ld8);
-  else
-    hipLaunchKernelGGL((igemm3_kernel<TM, TN, false>), grid, dim3(256), 0, st, p, p.src, (const uint4*)nullptr, (const uint4*)nullptr,
-                       (const uint4*)whi, (const uint4*)wlo, p.bias, p.addend, p.mask_src, p.out, w_rows, w_ld8);
+  // the branch-free loop needs a tap-linear gather and 31-bit byte offsets (see igemm3f_kernel)
+  static const bool fast_on = []() { const char* e = getenv("PP_CONV3_FAST"); return !(e && e[0] == '0'); }();
+  const long long a_bytes = p.src_rows * (long long)p.ld_src * (ahi ? 2 : 4);
+  const long long w_bytes = (long long)p.kh * p.kw * w_rows * w_ld8 * 16;
+  int max_sw = 0;
+  for (int i = 0; i < p.n_seg; ++i) max_sw = p.seg[i].SW > max_sw ? p.seg[i].SW : max_sw;
+  const bool fast = fast_on && p.div == 1 && p.kh * p.kw <= 31 && a_bytes < (1ll << 31) && w_bytes < (1ll << 31) &&
+                    (long long)max_sw * p.ld_src * 4 < (1ll << 23) && p.src_rows > 0;
+  auto go = [&](auto ap, auto op) {
+    constexpr bool AP = decltype(ap)::value, OP = decltype(op)::value;
+    if (fast)
+      hipLaunchKernelGGL((igemm3f_kernel<TM, TN, AP, OP>), grid, dim3(256), 0, st, p, AP ? ahi : (const void*)p.src, AP ? alo : nullptr,
+                         (unsigned)a_bytes, whi, wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)ohi, (uint2*)olo,
+                         w_rows, w_ld8);
+    else
+      hipLaunchKernelGGL((igemm3_kernel<TM, TN, AP, OP>), grid, dim3(256), 0, st, p, p.src, (const uint4*)(AP ? ahi : nullptr),
+                         (const uint4*)(AP ? alo : nullptr), (const uint4*)whi, (const uint4*)wlo, p.bias, p.addend, p.mask_src, p.out,
+                         (uint2*)ohi, (uint2*)olo, w_rows, w_ld8);
+  };
+  if (ahi && ohi) go(std::true_type{}, std::true_type{});
+  else if (ahi) go(std::true_type{}, std::false_type{});
+  else if (ohi) go(std::false_type{}, std::true_type{});
+  else go(std::false_type{}, std::false_type{});
 }
 
 static void pick_tile3(const pp_ctx* ctx, int M, int Nout, int* tm, int* tn) {
@@ -381,27 +625,27 @@ static void pick_tile3(const pp_ctx* ctx, int M, int Nout, int* tm, int* tn) {
 }
 
 static void dispatch3(pp_ctx* ctx, IgemmParams& p, const void* ahi, const void* alo, const void* whi, const void* wlo, int w_rows,
-                      int w_ld8) {
+                      int w_ld8, void* ohi, void* olo) {
   int tm, tn;
   pick_tile3(ctx, p.M, p.Nout, &tm, &tn);
-  if (tm == 4) launch_igemm3<4, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8);
-  else if (tm == 2 && tn == 2) launch_igemm3<2, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8);
-  else if (tm == 1 && tn == 2) launch_igemm3<1, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8);
-  else if (tm == 2 && tn == 1) launch_igemm3<2, 1>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8);
-  else launch_igemm3<1, 1>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8);
+  if (tm == 4) launch_igemm3<4, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo);
+  else if (tm == 2 && tn == 2) launch_igemm3<2, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo);
+  else if (tm == 1 && tn == 2) launch_igemm3<1, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo);
+  else if (tm == 2 && tn == 1) launch_igemm3<2, 1>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo);
+  else launch_igemm3<1, 1>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo);
 }
 
 extern "C" int pp_conv2d_nhwc_fwd_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const void* x_hi, const void* x_lo,
                                          const void* w_hi, const void* w_lo, const float* bias, const float* residual, int ld_res,
-                                         int relu, float* y) {
+                                         int relu, float* y, void* y_hi, void* y_lo) {
   PP_REQUIRE_CTX(ctx);
   int rc = check_desc(ctx, d, "pp_conv2d_nhwc_fwd_bf16x3");
   if (rc) return rc;
-  PP_CHECK_ARG(ctx, (x || (x_hi && x_lo)) && w_hi && w_lo && y, PP_ERR_ARG, "pp_conv2d_nhwc_fwd_bf16x3: null tensor");
+  PP_CHECK_ARG(ctx, (x || (x_hi && x_lo)) && w_hi && w_lo && (y || (y_hi && y_lo)), PP_ERR_ARG, "pp_conv2d_nhwc_fwd_bf16x3: null tensor");
   PP_CHECK_ARG(ctx, (x_hi == nullptr) == (x_lo == nullptr), PP_ERR_ARG, "pp_conv2d_nhwc_fwd_bf16x3: x_hi and x_lo go together");
   PP_CHECK_ARG(ctx, d->cin % 32 == 0 && d->ld_x % 8 == 0, PP_ERR_SHAPE, "pp_conv2d_nhwc_fwd_bf16x3: cin %d must be a multiple of 32, ld_x of 8", d->cin);
   PP_CHECK_ARG(ctx, !x_hi || (pp_is_aligned16(x_hi) && pp_is_aligned16(x_lo)), PP_ERR_ALIGN, "pp_conv2d_nhwc_fwd_bf16x3: plane alignment");
-  PP_CHECK_ARG(ctx, (!x || pp_is_aligned16(x)) && pp_is_aligned16(w_hi) && pp_is_aligned16(w_lo) && pp_is_aligned16(y), PP_ERR_ALIGN,
+  PP_CHECK_ARG(ctx, (!x || pp_is_aligned16(x)) && pp_is_aligned16(w_hi) && pp_is_aligned16(w_lo) && (!y || pp_is_aligned16(y)), PP_ERR_ALIGN,
                "pp_conv2d_nhwc_fwd_bf16x3: tensors must be 16-byte aligned");
   PP_CHECK_ARG(ctx, !residual || (ld_res % 4 == 0 && ld_res >= ((d->cout + 3) & ~3) && pp_is_aligned16(residual)), PP_ERR_SHAPE,
                "pp_conv2d_nhwc_fwd_bf16x3: residual");
@@ -412,27 +656,29 @@ extern "C" int pp_conv2d_nhwc_fwd_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, con
   p.ld_src = d->ld_x; p.ld_w = d->ld_w; p.ld_out = d->ld_y; p.ld_add = ld_res; p.ld_mask = 0;
   p.relu = relu;
   p.n_seg = d->in.n_seg;
-  fill_segs(ctx, d, true, p.seg, &p.M);
+  fill_segs(ctx, d, true, p.seg, &p.M, &p.src_rows);
   p.Cred = d->cin; p.Nout = d->cout; p.w_tap_rows = d->cin;
   p.kh = d->kh; p.kw = d->kw;
   p.mul = d->stride; p.tsign = 1; p.off_y = -d->pad_t; p.off_x = -d->pad_l; p.div = 1;
-  dispatch3(ctx, p, x_hi, x_lo, w_hi, w_lo, d->cout, d->cin / 8);
+  PP_CHECK_ARG(ctx, (y_hi == nullptr) == (y_lo == nullptr) && (!y_hi || (d->ld_y % 4 == 0 && pp_is_aligned16(y_hi) && pp_is_aligned16(y_lo))),
+               PP_ERR_ARG, "pp_conv2d_nhwc_fwd_bf16x3: output planes");
+  dispatch3(ctx, p, x_hi, x_lo, w_hi, w_lo, d->cout, d->cin / 8, y_hi, y_lo);
   PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_fwd_bf16x3");
   return PP_OK;
 }
 
 extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* dy, const void* dy_hi, const void* dy_lo,
                                               const void* w_hi, const void* w_lo, const float* addend, int ld_add,
-                                              const float* relu_src, int ld_rs, float* dx) {
+                                              const float* relu_src, int ld_rs, float* dx, void* dx_hi, void* dx_lo) {
   PP_REQUIRE_CTX(ctx);
   int rc = check_desc(ctx, d, "pp_conv2d_nhwc_bwd_data_bf16x3");
   if (rc) return rc;
-  PP_CHECK_ARG(ctx, (dy || (dy_hi && dy_lo)) && w_hi && w_lo && dx, PP_ERR_ARG, "pp_conv2d_nhwc_bwd_data_bf16x3: null tensor");
+  PP_CHECK_ARG(ctx, (dy || (dy_hi && dy_lo)) && w_hi && w_lo && (dx || (dx_hi && dx_lo)), PP_ERR_ARG, "pp_conv2d_nhwc_bwd_data_bf16x3: null tensor");
   PP_CHECK_ARG(ctx, (dy_hi == nullptr) == (dy_lo == nullptr) && d->ld_y % 8 == 0, PP_ERR_ARG, "pp_conv2d_nhwc_bwd_data_bf16x3: planes / ld_y");
   const int cred = (d->cout + 31) / 32 * 32;
   PP_CHECK_ARG(ctx, d->cin % 16 == 0 && d->ld_y >= cred && d->ld_y % 4 == 0, PP_ERR_SHAPE,
                "pp_conv2d_nhwc_bwd_data_bf16x3: dy needs ld_y >= %d (cout rounded up to 32, zero padded)", cred);
-  PP_CHECK_ARG(ctx, (!dy || pp_is_aligned16(dy)) && pp_is_aligned16(w_hi) && pp_is_aligned16(w_lo) && pp_is_aligned16(dx), PP_ERR_ALIGN,
+  PP_CHECK_ARG(ctx, (!dy || pp_is_aligned16(dy)) && pp_is_aligned16(w_hi) && pp_is_aligned16(w_lo) && (!dx || pp_is_aligned16(dx)), PP_ERR_ALIGN,
                "pp_conv2d_nhwc_bwd_data_bf16x3: tensors must be 16-byte aligned");
   PP_CHECK_ARG(ctx, (!addend || (ld_add >= d->cin && ld_add % 4 == 0 && pp_is_aligned16(addend))) &&
                         (!relu_src || (ld_rs >= d->cin && ld_rs % 4 == 0 && pp_is_aligned16(relu_src))),
@@ -443,11 +689,13 @@ extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d
   p.ld_src = d->ld_y; p.ld_w = d->ld_w; p.ld_out = d->ld_x; p.ld_add = ld_add; p.ld_mask = ld_rs;
   p.relu = 0;
   p.n_seg = d->in.n_seg;
-  fill_segs(ctx, d, false, p.seg, &p.M);
+  fill_segs(ctx, d, false, p.seg, &p.M, &p.src_rows);
   p.Cred = cred; p.Nout = d->cin; p.w_tap_rows = d->cin;
   p.kh = d->kh; p.kw = d->kw;
   p.mul = 1; p.tsign = -1; p.off_y = d->pad_t; p.off_x = d->pad_l; p.div = d->stride;
-  dispatch3(ctx, p, dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8);
+  PP_CHECK_ARG(ctx, (dx_hi == nullptr) == (dx_lo == nullptr) && (!dx_hi || (d->ld_x % 4 == 0 && pp_is_aligned16(dx_hi) && pp_is_aligned16(dx_lo))),
+               PP_ERR_ARG, "pp_conv2d_nhwc_bwd_data_bf16x3: output planes");
+  dispatch3(ctx, p, dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8, dx_hi, dx_lo);
   PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_data_bf16x3");
   return PP_OK;
 }
@@ -469,21 +717,8 @@ struct Wgrad3Params {
   int Cin, Cout;
   int kh, kw, stride, pad_t, pad_l;
   int k_tiles_per_tap, n_tiles_k, n_tiles_n, splits, rows_per_split;
+  long long src_rows;
 };
-
-__device__ __forceinline__ void split4(const float4& v4, uint2* out_hi, uint2* out_lo) {
-  const float v[4] = {v4.x, v4.y, v4.z, v4.w};
-  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-  bf16x4 h, l;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const __bf16 hh = (__bf16)v[j];
-    h[j] = hh;
-    l[j] = (__bf16)(v[j] - (float)hh);
-  }
-  *out_hi = *reinterpret_cast<uint2*>(&h);
-  *out_lo = *reinterpret_cast<uint2*>(&l);
-}
 
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned short* lds, int elem_off0, int elem_off1) {
   typedef __attribute__((address_space(3))) shortx4 lds_s4;
@@ -749,6 +984,259 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 2 : 3) void wgrad3_kernel(con
   }
 }
 
+// ---- wgrad3f: the same tiles with a branch-free k-loop (see igemm3f_kernel) ----
+// Every step each staging thread re-derives (image, y, x) of its pixel row from m with two reciprocal divisions
+// (exact for m < 2^24, host-checked) instead of the incremental walk with its data-dependent loops, addresses both
+// operands with 32-bit buffer offsets (out-of-range = zeros: padding taps, rows past the split, columns past ld_dy)
+// and converts the loaded tile while its MFMAs drain.  No 64-bit address registers -> 3 workgroups per CU at 128x128.
+__device__ __forceinline__ int div_small(int a, int b, float rcp_b, int* rem) {
+  int q = (int)((float)a * rcp_b);
+  int r = a - q * b;
+  const bool lo = r < 0;
+  q -= lo ? 1 : 0;
+  r += lo ? b : 0;
+  const bool hi = r >= b;
+  q += hi ? 1 : 0;
+  r -= hi ? b : 0;
+  *rem = r;
+  return q;
+}
+
+template <int TM, int TN, bool AP>
+__global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(const Wgrad3Params p, const void* __restrict__ g_x0,
+                                                                            const void* __restrict__ g_x1, unsigned x_bytes,
+                                                                            const void* __restrict__ g_d0, const void* __restrict__ g_d1,
+                                                                            unsigned d_bytes, float* __restrict__ g_dw,
+                                                                            float* __restrict__ g_dbias) {
+  constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32;
+  constexpr int PA = BM + 32, PB = BN + 32;  // LDS pitches in bf16 elements (row + 64 bytes)
+  constexpr int ES = AP ? 2 : 4;
+  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BK * (PA + PB)];
+  unsigned short* Xhi = smem;
+  unsigned short* Xlo = Xhi + BK * PA;
+  unsigned short* Ghi = Xlo + BK * PA;
+  unsigned short* Glo = Ghi + BK * PB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int b = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int tile_n = b % p.n_tiles_n;
+  b /= p.n_tiles_n;
+  const int tile_k = b % p.n_tiles_k;
+  const int split = b / p.n_tiles_k;
+  const int tap = tile_k / p.k_tiles_per_tap;
+  const int ci0 = (tile_k - tap * p.k_tiles_per_tap) * BM;
+  const int ty = tap / p.kw, tx = tap - ty * p.kw;
+  const int n0 = tile_n * BN;
+  const int m_begin = split * p.rows_per_split;
+  const int m_end = min(p.M, m_begin + p.rows_per_split);
+  const int n_steps = (m_end - m_begin + BK - 1) / BK;
+
+  const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_x0), 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(AP ? g_x1 : g_x0), 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_d0), 0, d_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(AP ? g_d1 : g_d0), 0, d_bytes, 0x00020000);
+
+  // staging: 8 threads per pixel row; thread q8 loads the 16-byte chunks q8 + 8*j of its row
+  const int prow = tid >> 3, q8 = tid & 7;
+  constexpr int QA = AP ? (BM / 64) : (BM / 32), QB = AP ? (BN / 64) : (BN / 32);  // 16-byte chunks per thread and operand
+  constexpr int CH = AP ? 8 : 4;                                                    // channels per chunk
+  uint4 ra[QA], rb[QB];                // f32 quads, or bf16 hi chunks (AP)
+  uint4 ral[AP ? QA : 1], rbl[AP ? QB : 1];  // bf16 lo chunks (AP)
+  uint2 sah[AP ? 1 : QA], sal[AP ? 1 : QA], sbh[AP ? 1 : QB], sbl[AP ? 1 : QB];  // converted tile (f32 path)
+  float4 bsum[BN / 32];
+#pragma unroll
+  for (int j = 0; j < BN / 32; ++j) bsum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool do_bias = (g_dbias != nullptr) && (tile_k == 0);
+  const float bmask = do_bias ? 1.f : 0.f;
+  int m_cur = m_begin + prow;
+
+  auto load_step = [&]() {
+    const int m = m_cur;
+    int rbeg = p.seg[0].row_begin, sb = p.seg[0].src_row_begin, OH = p.seg[0].OH, OW = p.seg[0].OW, SH = p.seg[0].SH, SW = p.seg[0].SW;
+    for (int s = 1; s < p.n_seg; ++s) {
+      const bool in = m >= p.seg[s].row_begin;
+      rbeg = in ? p.seg[s].row_begin : rbeg;
+      sb = in ? p.seg[s].src_row_begin : sb;
+      OH = in ? p.seg[s].OH : OH;
+      OW = in ? p.seg[s].OW : OW;
+      SH = in ? p.seg[s].SH : SH;
+      SW = in ? p.seg[s].SW : SW;
+    }
+    const bool in_rng = m < m_end;
+    const int local = in_rng ? m - rbeg : 0;
+    const int hw = OH * OW;
+    int rem, x;
+    const int n = div_small(local, hw, __frcp_rn((float)hw), &rem);
+    const int y = div_small(rem, OW, __frcp_rn((float)OW), &x);
+    const int sy = y * p.stride + ty - p.pad_t, sx = x * p.stride + tx - p.pad_l;
+    const bool ok = in_rng && ((unsigned)sy < (unsigned)SH) && ((unsigned)sx < (unsigned)SW);
+    int xo = ((sb + n * SH * SW + sy * SW + sx) * p.ld_src + ci0) * ES + 16 * q8;
+    xo = ok ? xo : PP_BUF_OOB;
+#pragma unroll
+    for (int j = 0; j < QA; ++j) {
+      ra[j] = buf_load16(rs_x0, xo, 128 * j);
+      if (AP) ral[j] = buf_load16(rs_x1, xo, 128 * j);
+    }
+    const int dyo = (m * p.ld_dy + n0) * ES + 16 * q8;
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+      const bool okb = in_rng && (n0 + CH * (q8 + 8 * j) < p.ld_dy);
+      const int o = okb ? dyo : PP_BUF_OOB;
+      rb[j] = buf_load16(rs_d0, o, 128 * j);
+      if (AP) rbl[j] = buf_load16(rs_d1, o, 128 * j);
+    }
+    m_cur += BK;
+  };
+  auto bf2f = [](unsigned int packed, float* lo_elem, float* hi_elem) {
+    *lo_elem = __uint_as_float(packed << 16);
+    *hi_elem = __uint_as_float(packed & 0xffff0000u);
+  };
+  auto split_step = [&]() {  // conversion (f32 path) and the bias partial sums: VALU only, issued under the MFMAs
+    if (AP) {
+#pragma unroll
+      for (int j = 0; j < QB; ++j) {  // dy = hi + lo (2^-17)
+        const unsigned int hw4[4] = {rb[j].x, rb[j].y, rb[j].z, rb[j].w}, lw4[4] = {rbl[j].x, rbl[j].y, rbl[j].z, rbl[j].w};
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float h0, h1, l0, l1;
+          bf2f(hw4[e], &h0, &h1);
+          bf2f(lw4[e], &l0, &l1);
+          v[2 * e] = h0 + l0;
+          v[2 * e + 1] = h1 + l1;
+        }
+        bsum[2 * j].x = fmaf(v[0], bmask, bsum[2 * j].x); bsum[2 * j].y = fmaf(v[1], bmask, bsum[2 * j].y);
+        bsum[2 * j].z = fmaf(v[2], bmask, bsum[2 * j].z); bsum[2 * j].w = fmaf(v[3], bmask, bsum[2 * j].w);
+        bsum[2 * j + 1].x = fmaf(v[4], bmask, bsum[2 * j + 1].x); bsum[2 * j + 1].y = fmaf(v[5], bmask, bsum[2 * j + 1].y);
+        bsum[2 * j + 1].z = fmaf(v[6], bmask, bsum[2 * j + 1].z); bsum[2 * j + 1].w = fmaf(v[7], bmask, bsum[2 * j + 1].w);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < QA; ++j) split4(*reinterpret_cast<const float4*>(&ra[j]), &sah[j], &sal[j]);
+#pragma unroll
+      for (int j = 0; j < QB; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(&rb[j]);
+        split4(v, &sbh[j], &sbl[j]);
+        bsum[j].x = fmaf(v.x, bmask, bsum[j].x); bsum[j].y = fmaf(v.y, bmask, bsum[j].y);
+        bsum[j].z = fmaf(v.z, bmask, bsum[j].z); bsum[j].w = fmaf(v.w, bmask, bsum[j].w);
+      }
+    }
+  };
+  auto store_step = [&]() {
+#pragma unroll
+    for (int j = 0; j < QA; ++j) {
+      const int off = prow * PA + CH * (q8 + 8 * j);
+      if (AP) {
+        *reinterpret_cast<uint4*>(Xhi + off) = ra[j];
+        *reinterpret_cast<uint4*>(Xlo + off) = ral[j];
+      } else {
+        *reinterpret_cast<uint2*>(Xhi + off) = sah[j];
+        *reinterpret_cast<uint2*>(Xlo + off) = sal[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+      const int off = prow * PB + CH * (q8 + 8 * j);
+      if (AP) {
+        *reinterpret_cast<uint4*>(Ghi + off) = rb[j];
+        *reinterpret_cast<uint4*>(Glo + off) = rbl[j];
+      } else {
+        *reinterpret_cast<uint2*>(Ghi + off) = sbh[j];
+        *reinterpret_cast<uint2*>(Glo + off) = sbl[j];
+      }
+    }
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int c = 0; c < TN; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+  // transposed-read lane roles (16-lane groups): group g -> columns 16*(g&1).., pixel half h = g>>1
+  const int grp = lane >> 4, gi = lane & 15, gq = gi >> 2, gp = gi & 3;
+  const int cbase = 16 * (grp & 1), hh = grp >> 1;
+  const int il = lane & 31, h = lane >> 5;
+
+  load_step();  // (n_steps == 0: every row is out of range -> zeros)
+  split_step();
+  store_step();
+  __syncthreads();
+  for (int step = 0; step < n_steps; ++step) {
+    load_step();  // past the last step m >= m_end: zeros, never stored
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      const int row0 = 16 * s + 8 * hh + gq;  // pixel row this lane addresses in the first transposed read
+      bf16x8 xh[TM], xl[TM], gh[TN], gl[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const int col = wm * 32 * TM + a * 32 + cbase + 4 * gp;
+        xh[a] = tr_frag(Xhi, row0 * PA + col, (row0 + 4) * PA + col);
+        xl[a] = tr_frag(Xlo, row0 * PA + col, (row0 + 4) * PA + col);
+      }
+#pragma unroll
+      for (int c = 0; c < TN; ++c) {
+        const int col = wn * 32 * TN + c * 32 + cbase + 4 * gp;
+        gh[c] = tr_frag(Ghi, row0 * PB + col, (row0 + 4) * PB + col);
+        gl[c] = tr_frag(Glo, row0 * PB + col, (row0 + 4) * PB + col);
+      }
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int c = 0; c < TN; ++c) {
+          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[a], gh[c], acc[a][c], 0, 0, 0);
+          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[a], gl[c], acc[a][c], 0, 0, 0);
+          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[a], gh[c], acc[a][c], 0, 0, 0);
+        }
+      if (s == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    split_step();
+    __syncthreads();
+    store_step();
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = ci0 + wm * 32 * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      float* dst = g_dw + (long long)(tap * p.Cin + ci) * p.ld_w;
+#pragma unroll
+      for (int c = 0; c < TN; ++c) {
+        const int co = n0 + wn * 32 * TN + c * 32 + il;
+        if (co < p.Cout) atomicAdd(dst + co, acc[a][c][r]);
+      }
+    }
+  }
+  if (do_bias) {
+    // 32 threads (one per pixel row of the step) hold partial sums of the same channels: reduce through LDS
+    float* red = reinterpret_cast<float*>(smem);  // [32][BN] floats <= LDS size
+    __syncthreads();
+    if (AP) {
+#pragma unroll
+      for (int j = 0; j < QB; ++j) {
+        *reinterpret_cast<float4*>(red + prow * BN + 8 * (q8 + 8 * j)) = bsum[2 * j];
+        *reinterpret_cast<float4*>(red + prow * BN + 8 * (q8 + 8 * j) + 4) = bsum[2 * j + 1];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < QB; ++j) *reinterpret_cast<float4*>(red + prow * BN + 4 * (q8 + 8 * j)) = bsum[j];
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) s += red[r * BN + tid];
+      if (n0 + tid < p.Cout) atomicAdd(g_dbias + n0 + tid, s);
+    }
+  }
+}
+
 template <int TM, int TN>
 static void launch_wgrad3(pp_ctx* ctx, Wgrad3Params& p, const float* x, const float* dy, const void* xhi, const void* xlo, const void* dhi,
                           const void* dlo, float* dw, float* dbias) {
@@ -761,7 +1249,11 @@ static void launch_wgrad3(pp_ctx* ctx, Wgrad3Params& p, const float* x, const fl
   int max_splits = (p.M + 511) / 512;  // at least 16 reduction steps of 32 rows per workgroup
   if (max_splits < 1) max_splits = 1;
   if (max_splits > 64) max_splits = 64;
-  const int slots = (TM * TN == 4) ? 2 : 3;
+  static const bool fast_on = []() { const char* e = getenv("PP_CONV3_FAST"); return !(e && e[0] == '0'); }();
+  const int es = xhi ? 2 : 4;
+  const long long x_bytes = p.src_rows * (long long)p.ld_src * es, d_bytes = (long long)p.M * p.ld_dy * es;
+  const bool fast = fast_on && x_bytes < (1ll << 31) && d_bytes < (1ll << 31) && p.M < (1 << 24) && p.src_rows > 0;
+  const int slots = fast ? ((TM * TN == 4) ? 3 : 4) : ((TM * TN == 4) ? 2 : 3);
   const double tile_work = (double)(TM * TN) / 4.0;
   const double atomic_us_per_split = (double)tiles * BM * BN * 4.0 / 1.3e6;
   int splits = 1;
@@ -774,12 +1266,24 @@ static void launch_wgrad3(pp_ctx* ctx, Wgrad3Params& p, const float* x, const fl
       splits = sp;
     }
   }
+  if (const char* e = getenv("PP_WGRAD3_SPLITS")) {  // tuning hook
+    const int v = atoi(e);
+    if (v >= 1 && v <= max_splits) splits = v;
+  }
+  if (getenv("PP_CONV_DEBUG")) fprintf(stderr, "wgrad3 tile %dx%d tiles %d splits %d (M %d) fast %d\n", BM, BN, tiles, splits, p.M, (int)fast);
   int rps = (p.M + splits - 1) / splits;
   rps = (rps + 31) / 32 * 32;
   splits = (p.M + rps - 1) / rps;
   p.splits = splits;
   p.rows_per_split = rps;
-  if (xhi)
+  if (fast) {
+    if (xhi)
+      hipLaunchKernelGGL((wgrad3f_kernel<TM, TN, true>), dim3((unsigned)(tiles * splits)), dim3(256), 0, ctx->stream, p, xhi, xlo,
+                         (unsigned)x_bytes, dhi, dlo, (unsigned)d_bytes, dw, dbias);
+    else
+      hipLaunchKernelGGL((wgrad3f_kernel<TM, TN, false>), dim3((unsigned)(tiles * splits)), dim3(256), 0, ctx->stream, p, (const void*)x,
+                         nullptr, (unsigned)x_bytes, (const void*)dy, nullptr, (unsigned)d_bytes, dw, dbias);
+  } else if (xhi)
     hipLaunchKernelGGL((wgrad3_kernel<TM, TN, true>), dim3((unsigned)(tiles * splits)), dim3(256), 0, ctx->stream, p, x, dy, (const uint4*)xhi,
                        (const uint4*)xlo, (const uint4*)dhi, (const uint4*)dlo, dw, dbias);
   else
@@ -804,7 +1308,7 @@ extern "C" int pp_conv2d_nhwc_bwd_weight_bf16x3(pp_ctx* ctx, const pp_conv_desc*
   memset(&p, 0, sizeof(p));
   p.ld_src = d->ld_x; p.ld_dy = d->ld_y; p.ld_w = d->ld_w;
   p.n_seg = d->in.n_seg;
-  fill_segs(ctx, d, true, p.seg, &p.M);
+  fill_segs(ctx, d, true, p.seg, &p.M, &p.src_rows);
   p.Cin = d->cin; p.Cout = d->cout;
   p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
   const bool big_k = (d->cin % 128 == 0);

@@ -34,6 +34,7 @@ struct IgemmParams {
   int kh, kw;
   int mul, tsign, off_y, off_x, div;  // src = (pos*mul + tap*tsign + off) / div
   int n_tiles_n;
+  long long src_rows;  // rows of the gathered tensor (all segments)
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8, each with a private L2).
@@ -106,7 +107,7 @@ __device__ __forceinline__ bool tap_offset(const IgemmParams& p, const RowPos& r
 
 
 // ---- host side ----
-static int fill_segs(pp_ctx* ctx, const pp_conv_desc* d, bool enumerate_out, SegGeo* seg, int* M_out) {
+static int fill_segs(pp_ctx* ctx, const pp_conv_desc* d, bool enumerate_out, SegGeo* seg, int* M_out, long long* src_rows_out = nullptr) {
   // enumerate_out: rows enumerate the OUTPUT space and gather from the input (fwd, wgrad);
   // otherwise rows enumerate the INPUT space and gather from the output-space tensor (bwd-data).
   const pp_rowspace* e = enumerate_out ? &d->out : &d->in;
@@ -121,6 +122,7 @@ static int fill_segs(pp_ctx* ctx, const pp_conv_desc* d, bool enumerate_out, Seg
     sb += (long long)g->n_img * g->h[s] * g->w[s];
   }
   *M_out = (int)rb;
+  if (src_rows_out) *src_rows_out = sb;
   (void)ctx;
   return 0;
 }

@@ -8,6 +8,7 @@ into the last data-gradient launch of each tensor (see DESIGN.md §Backward data
 Loss / optimizer = bin/train.py:95-102.
 """
 import math
+import os as _os
 from collections import OrderedDict
 
 import numpy as np
@@ -48,9 +49,25 @@ class Act(object):
         self.t = t if t is not None else torch.empty((self.rows, self.ld), dtype=torch.float32, device="cuda")
         self.needs_grad, self.relu = needs_grad, relu
         self.contribs = []
+        self.pl = None  # (hi, lo) int16 [rows, ld]: the same matrix pre-split into bf16 planes (bf16x3 mode, conv-produced)
 
     def rowspace(self):
         return RowSpace.make(self.n_img, self.shapes)
+
+
+def _new_planes(rows, ld):
+    return tuple(torch.zeros((rows, ld), dtype=torch.int16, device="cuda") for _ in range(2))
+
+
+class Grad(object):
+    """A gradient matrix and, when a bf16x3 kernel (or an explicit split) produced it, its bf16 planes."""
+    __slots__ = ("t", "pl")
+
+    def __init__(self, t, pl=None):
+        self.t, self.pl = t, pl
+
+    def rows(self, r0, r1):
+        return Grad(self.t[r0:r1], None if self.pl is None else (self.pl[0][r0:r1], self.pl[1][r0:r1]))
 
 
 class ParamStore(object):
@@ -174,14 +191,20 @@ class Engine(object):
         import os as _os
         self.conv_mode = conv_mode or _os.environ.get("PP_CONV_MODE", "bf16x3")
         assert self.conv_mode in ("f32", "bf16x3"), self.conv_mode
+        # PP_ACT_PLANES=1: conv epilogues also write their output pre-split into bf16 planes and the weight-gradient
+        # launches read both operands from planes (gradients that only convs read are then never stored in f32).
+        # Measured on the bench workload: bwd-weight -0.8 ms, forward + bwd-data epilogues +0.6..1.0 ms -> off by default.
+        self.use_act_planes = self.conv_mode == "bf16x3" and _os.environ.get("PP_ACT_PLANES", "0") == "1"
         self.planes = OrderedDict()  # spec name -> dict(desc, fwd_hi, fwd_lo, dg_hi, dg_lo)
         self.fwd_ops, self.graph_ops, self.bwd_ops = [], [], []
         # Launch lanes: lane 0 is the ctx stream; lanes 1-2 are side streams.  Independent kernel chains (the three
         # heads in forward; weight gradients vs the data-gradient chain in backward) are enqueued on different
         # lanes so that the tail of one launch (last, partially filled round of workgroups) is covered by
         # workgroups of another -- see DESIGN.md §Concurrency.  PP_LANES=1 serialises everything on lane 0.
+        # Measured (tools/phase_times.py, batch 8): forward 8.20 / 8.02 / 8.44 ms and backward 15.45 / 14.19 / 14.13 ms
+        # at 1 / 2 / 3 lanes -> two lanes (a third concurrent head chain only adds cache pressure).
         import os
-        self.n_lanes = max(1, min(3, int(os.environ.get("PP_LANES", "3"))))
+        self.n_lanes = max(1, min(3, int(os.environ.get("PP_LANES", "2"))))
         self.streams = [ctx.stream] + [torch.cuda.Stream(device=ctx.device) for _ in range(self.n_lanes - 1)]
         self.ctxs = [ctx] + [ops.Context(ctx.device, st) for st in self.streams[1:]]
         self._lane = 0
@@ -215,7 +238,7 @@ class Engine(object):
         self.acts[name] = a
         return a
 
-    def _conv(self, spec_name, x, out_name=None, relu=False, residual=None, out_t=None, out_ld=None):
+    def _conv(self, spec_name, x, out_name=None, relu=False, residual=None, out_t=None, out_ld=None, out_pl=None):
         s = self.params.specs[spec_name]
         k, st = s.k, s.stride
         cin_eff = 4 if s.cin == 3 else s.cin
@@ -254,11 +277,23 @@ class Engine(object):
                           dg_lo=torch.zeros((k * k, s.cin, _ru(s.cout, 32)), **i16) if need_dg else None)
                 self.planes[spec_name] = pl
             fh, fl = pl["fwd_hi"], pl["fwd_lo"]
-            self.fwd_ops.append(Op(lambda: ops.conv_fwd3(ctx, desc, x.t, fh, fl, b, rt, relu, y.t), "conv_fwd", spec_name, flops, None, lane))
+            if self.use_act_planes:
+                y.pl = out_pl if out_pl is not None else _new_planes(y.rows, y.ld)
+            # pre-split operands pay in the weight-gradient kernel (+25 %: its f32 path converts both operands in the
+            # loop); forward / bwd-data run equally fast from f32 (the conversion hides under their MFMAs), so planes
+            # are written only for tensors that a weight-gradient launch will read
+            if self._wants_planes(s):
+                x.conv3_consumers = getattr(x, "conv3_consumers", 0) + 1
+            y.producer = s
+            self.fwd_ops.append(Op(lambda: ops.conv_fwd3(ctx, desc, x.t, fh, fl, b, rt, relu, y.t, x.pl, y.pl), "conv_fwd", spec_name,
+                                   flops, None, lane))
         else:
             self.fwd_ops.append(Op(lambda: ops.conv_fwd(ctx, desc, x.t, w, b, rt, relu, y.t), "conv_fwd", spec_name, flops, None, lane))
         self.graph_ops.append(dict(kind="conv", spec=s, x=x, y=y, residual=residual, desc=desc, w=w, flops=flops, planes=pl))
         return y
+
+    def _wants_planes(self, s):
+        return self.train and s.trainable and s.cin % 64 == 0
 
     def _build_forward(self):
         B, H, W = self.B, self.H, self.W
@@ -301,15 +336,20 @@ class Engine(object):
         lv = [L3.shapes[0], L4.shapes[0], L5.shapes[0]]
         rows = [B * h * w for h, w in lv]
         pyr_t = torch.empty((sum(rows), 256), dtype=torch.float32, device="cuda")
-        sl = [pyr_t[0: rows[0]], pyr_t[rows[0]: rows[0] + rows[1]], pyr_t[rows[0] + rows[1]:]]
-        P3 = self._conv("P3", F3, out_t=sl[0])
+        cuts = [(0, rows[0]), (rows[0], rows[0] + rows[1]), (rows[0] + rows[1], sum(rows))]
+        sl = [pyr_t[a:b] for a, b in cuts]
+        pyr_pl = _new_planes(sum(rows), 256) if self.use_act_planes else None
+        spl = [(pyr_pl[0][a:b], pyr_pl[1][a:b]) if pyr_pl else None for a, b in cuts]
+        P3 = self._conv("P3", F3, out_t=sl[0], out_pl=spl[0])
         F4 = self._add("fpn_fin4", [D3, M4, L4])
         D4 = self._conv("fpn_down4", M4)
-        P4 = self._conv("P4", F4, out_t=sl[1])
+        P4 = self._conv("P4", F4, out_t=sl[1], out_pl=spl[1])
         F5 = self._add("fpn_fin5", [D4, L5])
-        P5 = self._conv("P5", F5, out_t=sl[2])
+        P5 = self._conv("P5", F5, out_t=sl[2], out_pl=spl[2])
         needs = self.train
         pyr = self._new_act("pyramid", lv, 256, 256, needs, False, pyr_t)
+        pyr.pl = pyr_pl
+        pyr.producer = getattr(P3, "producer", None)
         self.graph_ops.append(dict(kind="alias", y=pyr, parts=[P3, P4, P5], rows=rows))
         self.pyr, self.P3 = pyr, P3
         # ---- heads (models/retinanet.py:9-131, shared across levels :224-225; mask on P3 only :296)
@@ -335,6 +375,10 @@ class Engine(object):
                 if i < len(c):
                     mixed.append(c[i])
         self.fwd_ops = trunk + mixed
+        # planes nobody reads are not written (the forward closures read .pl at call time)
+        for a in self.acts.values():
+            if a.pl is not None and not getattr(a, "conv3_consumers", 0) and a.pl[0]._base is None:  # (P4/P5 write slices of pyr's)
+                a.pl = None
 
     def _upadd(self, name, src, other):
         (sh, sw), (th, tw) = src.shapes[0], other.shapes[0]
@@ -342,7 +386,16 @@ class Engine(object):
         ctx, B = self.ctx, self.B
         self.fwd_ops.append(Op(lambda: ops.upsample_add_fwd(ctx, B, sh, sw, th, tw, src.C, src.t, other.t, out.t), "pointwise", name))
         self.graph_ops.append(dict(kind="upadd", y=out, src=src, other=other))
+        self._split_act(out)
         return out
+
+    def _split_act(self, act):
+        """FPN sums feed trainable 3x3 convs: give them planes with an explicit split launch (their producer is not a conv)."""
+        if self.train and self.use_act_planes and act.ld % 8 == 0:
+            act.pl = _new_planes(act.rows, act.ld)
+            ctx = self.ctx
+            self.fwd_ops.append(Op(lambda: ops.split_planes3(ctx, act.t, act.pl[0], act.pl[1]) if act.pl is not None else None,
+                                   "pointwise", "split:" + act.name))
 
     def _add(self, name, ins):
         out = self._new_act(name, ins[0].shapes, ins[0].C, ins[0].ld, any(i.needs_grad for i in ins))
@@ -350,14 +403,17 @@ class Engine(object):
         a, b, c = ins[0].t, ins[1].t, (ins[2].t if len(ins) > 2 else None)
         self.fwd_ops.append(Op(lambda: ops.add_n(ctx, a, b, c, out.t), "pointwise", name))
         self.graph_ops.append(dict(kind="add", y=out, ins=ins))
+        self._split_act(out)
         return out
 
     # ------------------------------------------------------------------------------------ backward plan
-    def _finalize(self, act):
+    def _finalize(self, act, planes_only=False):
         """Sum the gradient contributions of `act`; the ReLU mask (act > 0) is folded into the last
-        data-gradient launch.  Returns the gradient w.r.t. the pre-activation, or None."""
+        data-gradient launch.  Returns the gradient w.r.t. the pre-activation, or None.
+        planes_only: every reader of the result takes bf16 planes -> the f32 copy is not written at all."""
         ctx = self.ctx
-        tensors = [c[1] for c in act.contribs if c[0] == "tensor"]
+        grads = [c[1] for c in act.contribs if c[0] == "tensor"]
+        tensors = [g.t for g in grads]
         dgrads = [c for c in act.contribs if c[0] == "dgrad"]
         if not tensors and not dgrads:
             return None
@@ -376,19 +432,33 @@ class Engine(object):
                 srcs, rest = [acc] + rest[:2], rest[2:]  # in-place accumulate (pointwise: safe)
         if act.relu and not dgrads:
             raise NotImplementedError("relu output %s without a data-gradient consumer" % act.name)
+        if not dgrads:
+            g = grads[0] if len(tensors) == 1 else Grad(acc)
+            prod = getattr(act, "producer", None)
+            if g.pl is None and self.use_act_planes and prod is not None and self._wants_planes(prod) and act.ld % 8 == 0:
+                g = Grad(g.t, _new_planes(act.rows, act.ld))
+                self.bwd_ops.append(Op(lambda gt=g.t, pl=g.pl: ops.split_planes3(ctx, gt, pl[0], pl[1]), "pointwise", "split:g:" + act.name))
+            return g
+        opl = None
         for i, (_, op, gy) in enumerate(dgrads):
             last = i == len(dgrads) - 1
-            out = new()
             mask = act.t if (act.relu and last) else None
             pl = op.get("planes")
             if pl is not None and pl["dg_hi"] is not None:
-                self.bwd_ops.append(Op(lambda d=op["desc"], gy=gy, dh=pl["dg_hi"], dl=pl["dg_lo"], acc=acc, mask=mask, out=out:
-                                       ops.conv_bwd_data3(ctx, d, gy, dh, dl, acc, mask, out), "conv_dgrad", op["spec"].name, op["flops"]))
+                prod = getattr(act, "producer", None)
+                # the finished gradient feeds the producer's dgrad/wgrad: hand it over pre-split
+                if last and self.use_act_planes and prod is not None and self._wants_planes(prod):
+                    opl = _new_planes(act.rows, act.ld)
+                out = None if (opl is not None and planes_only) else new()
+                self.bwd_ops.append(Op(lambda d=op["desc"], gy=gy, dh=pl["dg_hi"], dl=pl["dg_lo"], acc=acc, mask=mask, out=out, opl=opl:
+                                       ops.conv_bwd_data3(ctx, d, gy.t, dh, dl, acc, mask, out, gy.pl, opl), "conv_dgrad",
+                                       op["spec"].name, op["flops"]))
             else:
+                out = new()
                 self.bwd_ops.append(Op(lambda d=op["desc"], gy=gy, w=op["w"], acc=acc, mask=mask, out=out:
-                                       ops.conv_bwd_data(ctx, d, gy, w, acc, mask, out), "conv_dgrad", op["spec"].name, op["flops"]))
+                                       ops.conv_bwd_data(ctx, d, gy.t, w, acc, mask, out), "conv_dgrad", op["spec"].name, op["flops"]))
             acc = out
-        return acc
+        return Grad(acc, opl)
 
     def _build_backward(self):
         ctx, P = self.ctx, self.params
@@ -396,9 +466,12 @@ class Engine(object):
         self.g_reg = torch.zeros((self.reg_out.rows, self.reg_out.ld), **f32)
         self.g_cls = torch.zeros((self.cls_out.rows, self.cls_out.ld), **f32)
         self.g_mask = torch.zeros((self.mask_out.rows, self.mask_out.ld), **f32)
-        self.reg_out.contribs.append(("tensor", self.g_reg))
-        self.cls_out.contribs.append(("tensor", self.g_cls))
-        self.mask_out.contribs.append(("tensor", self.g_mask))
+        for out, gt in ((self.reg_out, self.g_reg), (self.cls_out, self.g_cls), (self.mask_out, self.g_mask)):
+            g = Grad(gt)
+            if self.use_act_planes:
+                g.pl = _new_planes(out.rows, out.ld)
+                self.bwd_ops.append(Op(lambda gt=gt, pl=g.pl: ops.split_planes3(ctx, gt, pl[0], pl[1]), "pointwise", "split:" + out.name))
+            out.contribs.append(("tensor", g))
         for op in reversed(self.graph_ops):
             kind = op["kind"]
             if kind == "stop":
@@ -406,7 +479,16 @@ class Engine(object):
             y = op["y"]
             if not y.needs_grad:
                 continue
-            g = self._finalize(y)
+            po = False
+            if kind == "conv" and self.use_act_planes:
+                # the gradient of a conv output is read by that conv's bwd-data and bwd-weight launches only (plus its
+                # residual input, in f32): when both take planes, the f32 copy of the gradient is never materialised
+                s_, x_, r_ = op["spec"], op["x"], op["residual"]
+                pl_ = op.get("planes")
+                dgrad3_ok = (not x_.needs_grad) or (pl_ is not None and pl_["dg_hi"] is not None)
+                wgrad3_ok = (not s_.trainable) or (s_.cin % 64 == 0 and x_.pl is not None)
+                po = dgrad3_ok and wgrad3_ok and not (r_ is not None and r_.needs_grad) and self._wants_planes(s_)
+            g = self._finalize(y, po)
             if g is None:
                 continue
             if kind == "conv":
@@ -419,9 +501,13 @@ class Engine(object):
                     wr = (ek["offset"], eb["offset"] + eb["count"])
                     wl = 1 % self.n_lanes
                     wctx = self.ctxs[wl]
-                    wfn = ops.conv_bwd_weight3 if (self.conv_mode == "bf16x3" and s.cin % 64 == 0) else ops.conv_bwd_weight
-                    self.bwd_ops.append(Op(lambda d=op["desc"], xt=x.t, g=g, dw=dw, db=db, wctx=wctx, wfn=wfn: wfn(wctx, d, xt, g, dw, db),
-                                           "conv_wgrad", s.name, op["flops"], wr, wl))
+                    if self.conv_mode == "bf16x3" and s.cin % 64 == 0:
+                        both = x.pl is not None and g.pl is not None
+                        fn = lambda d=op["desc"], x=x, g=g, dw=dw, db=db, wctx=wctx, xp=(x.pl if both else None), gp=(g.pl if both else None): \
+                            ops.conv_bwd_weight3(wctx, d, x.t, g.t, dw, db, xp, gp)
+                    else:
+                        fn = lambda d=op["desc"], xt=x.t, g=g, dw=dw, db=db, wctx=wctx: ops.conv_bwd_weight(wctx, d, xt, g.t, dw, db)
+                    self.bwd_ops.append(Op(fn, "conv_wgrad", s.name, op["flops"], wr, wl))
                 if x.needs_grad:
                     x.contribs.append(("dgrad", op, g))
                 r = op["residual"]
@@ -439,12 +525,12 @@ class Engine(object):
                     gs = torch.empty((src.rows, src.ld), **f32)
                     (sh, sw), (th, tw) = src.shapes[0], other.shapes[0]
                     self.bwd_ops.append(Op(lambda g=g, gs=gs, sh=sh, sw=sw, th=th, tw=tw, c=src.C:
-                                           ops.upsample_add_bwd(ctx, self.B, sh, sw, th, tw, c, g, None, gs), "pointwise", "upbwd:" + src.name))
-                    src.contribs.append(("tensor", gs))
+                                           ops.upsample_add_bwd(ctx, self.B, sh, sw, th, tw, c, g.t, None, gs), "pointwise", "upbwd:" + src.name))
+                    src.contribs.append(("tensor", Grad(gs)))
             elif kind == "alias":
                 r0 = 0
                 for part, n in zip(op["parts"], op["rows"]):
-                    part.contribs.append(("tensor", g[r0: r0 + n]))
+                    part.contribs.append(("tensor", g.rows(r0, r0 + n)))
                     r0 += n
 
     # ------------------------------------------------------------------------------------ execution

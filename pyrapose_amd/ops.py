@@ -85,19 +85,23 @@ def split_planes3(ctx, src, hi, lo):
     check(lib.pp_split_planes_bf16x3(ctx.handle, src.numel(), _ptr(src), _ptr(hi), _ptr(lo)), ctx.handle, "pp_split_planes_bf16x3")
 
 
-def conv_fwd3(ctx, d, x, w_hi, w_lo, bias, residual, relu, y, x_planes=None):
+def conv_fwd3(ctx, d, x, w_hi, w_lo, bias, residual, relu, y, x_planes=None, y_planes=None):
     ld_res = residual.stride(0) if residual is not None else 0
     xh, xl = x_planes if x_planes is not None else (None, None)
+    yh, yl = y_planes if y_planes is not None else (None, None)
     check(lib.pp_conv2d_nhwc_fwd_bf16x3(ctx.handle, C.byref(d), _ptr(x), _ptr(xh), _ptr(xl), _ptr(w_hi), _ptr(w_lo), _ptr(bias),
-                                        _ptr(residual), ld_res, int(bool(relu)), _ptr(y)), ctx.handle, "pp_conv2d_nhwc_fwd_bf16x3")
+                                        _ptr(residual), ld_res, int(bool(relu)), _ptr(y), _ptr(yh), _ptr(yl)), ctx.handle,
+          "pp_conv2d_nhwc_fwd_bf16x3")
 
 
-def conv_bwd_data3(ctx, d, dy, w_hi, w_lo, addend, relu_src, dx, dy_planes=None):
+def conv_bwd_data3(ctx, d, dy, w_hi, w_lo, addend, relu_src, dx, dy_planes=None, dx_planes=None):
     ld_add = addend.stride(0) if addend is not None else 0
     ld_rs = relu_src.stride(0) if relu_src is not None else 0
     dh, dl = dy_planes if dy_planes is not None else (None, None)
+    xh, xl = dx_planes if dx_planes is not None else (None, None)
     check(lib.pp_conv2d_nhwc_bwd_data_bf16x3(ctx.handle, C.byref(d), _ptr(dy), _ptr(dh), _ptr(dl), _ptr(w_hi), _ptr(w_lo), _ptr(addend),
-                                             ld_add, _ptr(relu_src), ld_rs, _ptr(dx)), ctx.handle, "pp_conv2d_nhwc_bwd_data_bf16x3")
+                                             ld_add, _ptr(relu_src), ld_rs, _ptr(dx), _ptr(xh), _ptr(xl)), ctx.handle,
+          "pp_conv2d_nhwc_bwd_data_bf16x3")
 
 
 def conv_bwd_weight3(ctx, d, x, dy, dw, dbias, x_planes=None, dy_planes=None):

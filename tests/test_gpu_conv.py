@@ -277,8 +277,13 @@ def test_conv_bf16x3_fwd_bwd_data(ctx, case):
     ops.split_planes3(ctx, x, xh, xl)
     assert rel_err((xh.view(torch.bfloat16).float() + xl.view(torch.bfloat16).float()).cpu().numpy(), x.cpu().numpy()) < 2e-5
     y2 = torch.full_like(y, float("nan"))
-    ops.conv_fwd3(ctx, d, None, fh, fl, bd.cuda(), _cat_rows(res, ld_y), True, y2, x_planes=(xh, xl))
+    yh, yl = torch.zeros_like(y, dtype=torch.int16), torch.zeros_like(y, dtype=torch.int16)
+    ops.conv_fwd3(ctx, d, None, fh, fl, bd.cuda(), _cat_rows(res, ld_y), True, y2, x_planes=(xh, xl), y_planes=(yh, yl))
     assert torch.equal(y2[:, :cout], y[:, :cout])
+    # ... and the epilogue's pre-split copy of the output is exactly what the split kernel makes of it
+    wh, wl = torch.zeros_like(yh), torch.zeros_like(yl)
+    ops.split_planes3(ctx, torch.nan_to_num(y2), wh, wl)
+    assert torch.equal(yh[:, :cout], wh[:, :cout]) and torch.equal(yl[:, :cout], wl[:, :cout])
     # bwd-data against float64 autograd
     xg = [t.clone().requires_grad_(True) for t in xs]
     wt = torch.as_tensor(w, dtype=torch.float64)
@@ -304,8 +309,12 @@ def test_conv_bf16x3_fwd_bwd_data(ctx, case):
     gh, gl = torch.zeros_like(gy, dtype=torch.int16), torch.zeros_like(gy, dtype=torch.int16)
     ops.split_planes3(ctx, gy, gh, gl)
     dx2 = torch.full_like(dx, float("nan"))
-    ops.conv_bwd_data3(ctx, d, None, dh, dl, _cat_rows(addend), _cat_rows(rsrc), dx2, dy_planes=(gh, gl))
+    xh2, xl2 = torch.zeros_like(dx, dtype=torch.int16), torch.zeros_like(dx, dtype=torch.int16)
+    ops.conv_bwd_data3(ctx, d, None, dh, dl, _cat_rows(addend), _cat_rows(rsrc), dx2, dy_planes=(gh, gl), dx_planes=(xh2, xl2))
     assert torch.equal(dx2, dx)
+    wh, wl = torch.zeros_like(xh2), torch.zeros_like(xl2)
+    ops.split_planes3(ctx, dx2, wh, wl)
+    assert torch.equal(xh2, wh) and torch.equal(xl2, wl)
 
 
 WG3_CASES = [c for c in CASES if c[3] % 64 == 0]

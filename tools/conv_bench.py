@@ -28,6 +28,9 @@ SHAPES = {
     "res2c": (8, [(120, 160)], 64, 256, 1, 1, 0),
     "res2b": (8, [(120, 160)], 64, 64, 3, 1, 1),
     # occupancy probes: exactly 1024 / 512 / 256 / 2048 workgroups of 128x128 at cout 512
+    "r3": (18, [(64, 64)], 512, 512, 3, 1, 1),     # 128x128 tiles: 576*4 = 2304 workgroups = exactly 3 rounds of 3 per CU
+    "r2": (12, [(64, 64)], 512, 512, 3, 1, 1),     # exactly 2 rounds
+    "r2t": (13, [(64, 64)], 512, 512, 3, 1, 1),    # 2 rounds + 8 %
     "occ4": (8, [(64, 64)], 512, 512, 3, 1, 1),
     "occ2": (4, [(64, 64)], 512, 512, 3, 1, 1),
     "occ1": (2, [(64, 64)], 512, 512, 3, 1, 1),
@@ -71,7 +74,11 @@ def main():
         gh, gl = torch.zeros_like(dy, dtype=torch.int16), torch.zeros_like(dy, dtype=torch.int16)
         ops.split_planes3(ctx, x, xh, xl)
         ops.split_planes3(ctx, dy, gh, gl)
-        fns = {"fwd3p": lambda: ops.conv_fwd3(ctx, d, None, fh, fl, bias, None, True, y, x_planes=(xh, xl)),
+        yh, yl = torch.zeros((rows, ld_w), **i16), torch.zeros((rows, ld_w), **i16)
+        dxh, dxl = torch.zeros((rows, cin), **i16), torch.zeros((rows, cin), **i16)
+        fns = {"fwd3pp": lambda: ops.conv_fwd3(ctx, d, None, fh, fl, bias, None, True, y, x_planes=(xh, xl), y_planes=(yh, yl)),
+               "dgrad3pp": lambda: ops.conv_bwd_data3(ctx, d, None, dh, dl, None, x, dx, dy_planes=(gh, gl), dx_planes=(dxh, dxl)),
+               "fwd3p": lambda: ops.conv_fwd3(ctx, d, None, fh, fl, bias, None, True, y, x_planes=(xh, xl)),
                "dgrad3p": lambda: ops.conv_bwd_data3(ctx, d, None, dh, dl, None, x, dx, dy_planes=(gh, gl)),
                "wgrad3p": lambda: ops.conv_bwd_weight3(ctx, d, None, None, dw, db, x_planes=(xh, xl), dy_planes=(gh, gl)),
                "splitx": lambda: ops.split_planes3(ctx, x, xh, xl),
