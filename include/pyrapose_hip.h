@@ -101,6 +101,16 @@ int pp_conv2d_nhwc_bwd_weight(pp_ctx* ctx, const pp_conv_desc* d, const float* x
  * Any of the plane pairs may be NULL in pp_conv_split_weights_bf16x3. */
 int pp_conv_split_weights_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* w, void* fwd_hi, void* fwd_lo,
                                  void* dgrad_hi, void* dgrad_lo);
+/* The same for many tensors in one launch.  jobs_dev: DEVICE array of n_jobs entries; job i owns the tiles
+ * [tile_begin, tile_begin + taps * (cin/32) * ceil(cout/32)) of the launch, tile_begin ascending from 0;
+ * total_tiles = the sum.  Plane pointers as in pp_conv_split_weights_bf16x3 (either pair may be NULL). */
+typedef struct pp_split_job {
+  const float* w;      /* f32 HWIO [taps*cin][ld_w] */
+  void* fwd_hi; void* fwd_lo; void* dg_hi; void* dg_lo;
+  int taps, cin, cout, ld_w;
+  int tile_begin, reserved;
+} pp_split_job;
+int pp_conv_split_weights_bf16x3_batch(pp_ctx* ctx, int n_jobs, const pp_split_job* jobs_dev, int total_tiles);
 /* f32 tensor of n elements (n % 8 == 0) -> bf16 (hi, lo) planes with the same [rows][ld] geometry.  Convs that are
  * given planes for their gathered operand skip the conversion inside the kernel (the f32 pointer may then be NULL). */
 int pp_split_planes_bf16x3(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo);

@@ -46,6 +46,11 @@ class ParamDesc(C.Structure):
                 ("scale_off", C.c_longlong), ("l2", C.c_float)]
 
 
+class SplitJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("fwd_hi", C.c_void_p), ("fwd_lo", C.c_void_p), ("dg_hi", C.c_void_p), ("dg_lo", C.c_void_p),
+                ("taps", C.c_int), ("cin", C.c_int), ("cout", C.c_int), ("ld_w", C.c_int), ("tile_begin", C.c_int), ("reserved", C.c_int)]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -78,6 +83,7 @@ _SIGS = {
     "pp_conv2d_nhwc_bwd_weight": (_i, [_p, C.POINTER(ConvDesc), _p, _p, _p, _p]),
     "pp_conv_split_weights_bf16x3": (_i, [_p, C.POINTER(ConvDesc), _p, _p, _p, _p, _p]),
     "pp_split_planes_bf16x3": (_i, [_p, _sz, _p, _p, _p]),
+    "pp_conv_split_weights_bf16x3_batch": (_i, [_p, _i, _p, _i]),
     "pp_conv2d_nhwc_fwd_bf16x3": (_i, [_p, C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "pp_conv2d_nhwc_bwd_data_bf16x3": (_i, [_p, C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p]),
     "pp_conv2d_nhwc_bwd_weight_bf16x3": (_i, [_p, C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),

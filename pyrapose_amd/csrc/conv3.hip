@@ -516,12 +516,11 @@ extern "C" int pp_split_planes_bf16x3(pp_ctx* ctx, size_t n, const float* src, v
 }
 
 // ---- weight split: f32 HWIO [tap*cin + ci][ld_w] -> bf16 hi/lo planes in both k-contiguous layouts ----
-__global__ void split_weights_kernel(int taps, int cin, int cout, int ld_w, const float* __restrict__ w,
-                                     unsigned short* __restrict__ fwd_hi, unsigned short* __restrict__ fwd_lo, int cout_rows,
-                                     unsigned short* __restrict__ dg_hi, unsigned short* __restrict__ dg_lo, int dg_ld) {
+__device__ __forceinline__ void split_weights_tile(int tap, int ci0, int co0, int cin, int cout, int ld_w, const float* __restrict__ w,
+                                                   unsigned short* __restrict__ fwd_hi, unsigned short* __restrict__ fwd_lo, int cout_rows,
+                                                   unsigned short* __restrict__ dg_hi, unsigned short* __restrict__ dg_lo, int dg_ld) {
   // 32x32 (ci x co) tiles through LDS so that both layouts are written with contiguous rows
   __shared__ unsigned short t_hi[32][33], t_lo[32][33];
-  const int tap = blockIdx.z, ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
   const int tx = threadIdx.x, ty = threadIdx.y;  // 32 x 8
   for (int j = ty; j < 32; j += 8) {
     const int ci = ci0 + j, co = co0 + tx;
@@ -549,6 +548,39 @@ __global__ void split_weights_kernel(int taps, int cin, int cout, int ld_w, cons
       }
     }
   }
+}
+
+__global__ void split_weights_kernel(int taps, int cin, int cout, int ld_w, const float* __restrict__ w,
+                                     unsigned short* __restrict__ fwd_hi, unsigned short* __restrict__ fwd_lo, int cout_rows,
+                                     unsigned short* __restrict__ dg_hi, unsigned short* __restrict__ dg_lo, int dg_ld) {
+  split_weights_tile(blockIdx.z, blockIdx.y * 32, blockIdx.x * 32, cin, cout, ld_w, w, fwd_hi, fwd_lo, cout_rows, dg_hi, dg_lo, dg_ld);
+}
+
+// every tensor of a model in ONE launch (the optimizer step re-splits ~80 tensors; 80 launches of ~5 us were 2 % of a step)
+__global__ void split_weights_batch_kernel(int n_jobs, const pp_split_job* __restrict__ jobs) {
+  int lo = 0, hi = n_jobs - 1;  // last job with tile_begin <= blockIdx.x (uniform)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].tile_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const pp_split_job j = jobs[lo];
+  const int dg_ld = (j.cout + 31) / 32 * 32;
+  const int tiles_co = dg_ld / 32, tiles_ci = j.cin / 32;
+  int t = (int)blockIdx.x - j.tile_begin;
+  const int co_t = t % tiles_co;
+  t /= tiles_co;
+  const int ci_t = t % tiles_ci, tap = t / tiles_ci;
+  split_weights_tile(tap, ci_t * 32, co_t * 32, j.cin, j.cout, j.ld_w, j.w, (unsigned short*)j.fwd_hi, (unsigned short*)j.fwd_lo, j.cout,
+                     (unsigned short*)j.dg_hi, (unsigned short*)j.dg_lo, dg_ld);
+}
+
+extern "C" int pp_conv_split_weights_bf16x3_batch(pp_ctx* ctx, int n_jobs, const pp_split_job* jobs_dev, int total_tiles) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, n_jobs >= 0 && total_tiles >= 0 && (n_jobs == 0 || jobs_dev), PP_ERR_ARG, "pp_conv_split_weights_bf16x3_batch: bad arguments");
+  if (n_jobs == 0 || total_tiles == 0) return PP_OK;
+  hipLaunchKernelGGL(split_weights_batch_kernel, dim3((unsigned)total_tiles), dim3(32, 8), 0, ctx->stream, n_jobs, jobs_dev);
+  PP_CHECK_LAUNCH(ctx, "pp_conv_split_weights_bf16x3_batch");
+  return PP_OK;
 }
 
 extern "C" int pp_conv_split_weights_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* w, void* fwd_hi, void* fwd_lo,

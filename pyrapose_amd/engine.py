@@ -613,11 +613,15 @@ class Engine(object):
         self._join(list(range(1, self.n_lanes)))
 
     def refresh_planes(self, only_trainable=False):
-        """Re-split the effective weights into the bf16 (hi, lo) planes of the bf16x3 kernels."""
-        for name, pl in self.planes.items():
-            if only_trainable and not self.params.specs[name].trainable:
-                continue
-            ops.conv_split_weights3(self.ctx, pl["desc"], pl["w"], pl["fwd_hi"], pl["fwd_lo"], pl["dg_hi"], pl["dg_lo"])
+        """Re-split the effective weights into the bf16 (hi, lo) planes of the bf16x3 kernels (one launch)."""
+        key = "_split_trainable" if only_trainable else "_split_all"
+        batch = getattr(self, key, None)
+        if batch is None:
+            batch = ops.SplitWeightsBatch((pl["desc"], pl["w"], pl["fwd_hi"], pl["fwd_lo"], pl["dg_hi"], pl["dg_lo"])
+                                          for name, pl in self.planes.items()
+                                          if not only_trainable or self.params.specs[name].trainable)
+            setattr(self, key, batch)
+        batch.run(self.ctx)
 
     def optimizer_step(self):
         P = self.params

@@ -81,6 +81,32 @@ def conv_split_weights3(ctx, d, w, fwd_hi, fwd_lo, dg_hi, dg_lo):
           ctx.handle, "pp_conv_split_weights_bf16x3")
 
 
+class SplitWeightsBatch(object):
+    """Job table (device resident) for pp_conv_split_weights_bf16x3_batch: every listed tensor is re-split by one launch."""
+
+    def __init__(self, jobs):
+        """jobs: iterable of (desc, w, fwd_hi, fwd_lo, dg_hi, dg_lo) as for conv_split_weights3."""
+        from ._lib import SplitJob
+        jobs = list(jobs)
+        arr = (SplitJob * max(len(jobs), 1))()
+        tiles = 0
+        self._keep = jobs  # the table holds raw pointers into these tensors
+        for i, (d, w, fh, fl, dh, dl) in enumerate(jobs):
+            if d.cin % 32:
+                raise ValueError("SplitWeightsBatch: cin %d must be a multiple of 32" % d.cin)
+            j = arr[i]
+            j.w, j.fwd_hi, j.fwd_lo, j.dg_hi, j.dg_lo = [(t.data_ptr() if t is not None else None) for t in (w, fh, fl, dh, dl)]
+            j.taps, j.cin, j.cout, j.ld_w, j.tile_begin = d.kh * d.kw, d.cin, d.cout, d.ld_w, tiles
+            tiles += j.taps * (d.cin // 32) * ((d.cout + 31) // 32)
+        self.n, self.tiles = len(jobs), tiles
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.table = host.cuda()
+
+    def run(self, ctx):
+        check(lib.pp_conv_split_weights_bf16x3_batch(ctx.handle, self.n, _ptr(self.table), self.tiles), ctx.handle,
+              "pp_conv_split_weights_bf16x3_batch")
+
+
 def split_planes3(ctx, src, hi, lo):
     check(lib.pp_split_planes_bf16x3(ctx.handle, src.numel(), _ptr(src), _ptr(hi), _ptr(lo)), ctx.handle, "pp_split_planes_bf16x3")
 

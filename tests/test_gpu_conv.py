@@ -365,3 +365,31 @@ def test_conv_bf16x3_bwd_weight(ctx, case):
     ops.conv_bwd_weight3(ctx, d, None, None, dw2, db2, x_planes=(xh, xl), dy_planes=(gh, gl))
     assert rel_err(dw2.cpu().numpy()[:, :cout], gw_ref.reshape(-1, cout).numpy()) < 1e-4
     assert rel_err(db2.cpu().numpy()[:cout], db_ref) < 5e-5
+
+
+def test_split_weights_batch_matches_per_tensor(ctx):
+    """pp_conv_split_weights_bf16x3_batch: one launch over several tensors == the per-tensor launches, bit for bit."""
+    from pyrapose_amd import ops
+    rng = np.random.default_rng(5)
+    jobs, want = [], []
+    i16 = dict(dtype=torch.int16, device="cuda")
+    for (cin, cout, k, need_dg) in [(64, 144, 3, True), (256, 13, 3, True), (128, 512, 1, False), (32, 32, 1, True)]:
+        ld_w = (cout + 15) // 16 * 16
+        d = ops.make_conv_desc(1, [(8, 8)], [(8, 8)], cin, cout, k, 1, k // 2, k // 2, cin, (cout + 31) // 32 * 32, ld_w)
+        w = torch.zeros((k * k * cin, ld_w), dtype=torch.float32, device="cuda")
+        w[:, :cout] = torch.as_tensor(rng.standard_normal((k * k * cin, cout)), dtype=torch.float32).cuda()
+        mk = lambda shape: (torch.full(shape, -1, **i16), torch.full(shape, -1, **i16))
+        dg_shape = (k * k, cin, (cout + 31) // 32 * 32)
+        a = mk((k * k, cout, cin)) + (mk(dg_shape) if need_dg else (None, None))
+        b = mk((k * k, cout, cin)) + (mk(dg_shape) if need_dg else (None, None))
+        ops.conv_split_weights3(ctx, d, w, *a)
+        jobs.append((d, w) + b)
+        want.append((a, b))
+    batch = ops.SplitWeightsBatch(jobs)
+    batch.run(ctx)
+    torch.cuda.synchronize()
+    for a, b in want:
+        for ta, tb in zip(a, b):
+            assert (ta is None) == (tb is None)
+            if ta is not None:
+                assert torch.equal(ta, tb)
