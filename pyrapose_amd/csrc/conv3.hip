@@ -321,7 +321,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
     const IgemmParams p, const void* __restrict__ g_a0, const void* __restrict__ g_a1, unsigned a_bytes,
     const void* __restrict__ g_whi, const void* __restrict__ g_wlo, unsigned w_bytes,
     const float* __restrict__ g_bias, const float* __restrict__ g_addend, const float* __restrict__ g_mask,
-    float* __restrict__ g_out, uint2* __restrict__ g_ohi, uint2* __restrict__ g_olo, int w_rows, int w_ld8) {
+    float* __restrict__ g_out, uint2* __restrict__ g_ohi, uint2* __restrict__ g_olo, int w_rows, int w_ld8, int splits,
+    float* __restrict__ g_ws) {
   constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, NO = BK / 8;
   constexpr int SMEM_U4 = 2 * NO * (BM + BN);
   constexpr int ES = AP ? 2 : 4;  // bytes per gathered element
@@ -333,12 +334,15 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int lb = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int lbs = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int split = lbs % splits, lb = lbs / splits;  // split-K: `splits` workgroups share one output tile
   const int tile_n = lb % p.n_tiles_n, tile_m = lb / p.n_tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int oct = tid & 3, r0 = tid >> 2;
   const int n_taps = p.kh * p.kw;
-  const int n_steps = n_taps * (p.Cred / BK);
+  const int steps_per_tap = p.Cred / BK;
+  const int all_steps = n_taps * steps_per_tap;
+  const int s_begin = (int)((long long)all_steps * split / splits), s_end = (int)((long long)all_steps * (split + 1) / splits);
 
   const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_a0), 0, a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(AP ? g_a1 : g_a0), 0, a_bytes, 0x00020000);
@@ -374,7 +378,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
   float4 ra[TM][2];
   uint4 rah[TM], ral[TM];
   uint4 rbh[TN], rbl[TN];
-  int tap = 0, ty = 0, tx = 0, red0 = 0;
+  int tap = s_begin / steps_per_tap, red0 = (s_begin - tap * steps_per_tap) * BK;
+  int ty = tap / p.kw, tx = tap - ty * p.kw;
 
   auto load_step = [&]() {
     const int a_uni = tx * x_pitch + red0 * ES;
@@ -448,8 +453,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
   store_step();
   __syncthreads();
 
-  for (int step = 0; step < n_steps; ++step) {
-    advance(step + 1 < n_steps);
+  for (int step = s_begin; step < s_end; ++step) {
+    advance(step + 1 < s_end);
     load_step();  // in flight under the MFMAs below
     // (left alone the scheduler sinks the loads below the MFMAs, or pulls the conversion of the loaded tile -- and
     // with it the wait for the loads -- up to the first MFMA: pin loads | first half of the MFMAs | rest + conversion)
@@ -489,7 +494,45 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
     store_step();
     __syncthreads();
   }
+  if (splits > 1) {  // partial sums only: splitk_finish_kernel applies the epilogue once every split has landed
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          const int co = n0 + wn * 32 * TN + b * 32 + il;
+          if (m < p.M && co < p.Nout) unsafeAtomicAdd(g_ws + (long long)m * p.ld_out + co, acc[a][b][r]);
+        }
+      }
+    return;
+  }
   epilogue3<TM, TN, OP, 4>(p, acc, smem, m0, n0, tid, wm, wn, il, h, g_bias, g_addend, g_mask, g_out, g_ohi, g_olo);
+}
+
+// out = relu?(mask?(ws + bias + addend)) over [M][ceil4(Nout)], and ws := 0 again (the workspace invariant)
+__global__ void splitk_finish_kernel(const IgemmParams p, float* __restrict__ ws, const float* __restrict__ g_bias,
+                                     const float* __restrict__ g_addend, const float* __restrict__ g_mask, float* __restrict__ g_out) {
+  const int n4 = (p.Nout + 3) >> 2;
+  const long long total = (long long)p.M * n4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / n4), co = 4 * (int)(i - (long long)m * n4);
+    float4* w4 = reinterpret_cast<float4*>(ws + (long long)m * p.ld_out + co);
+    float4 v = *w4;
+    *w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g_bias) { const float4 b = *reinterpret_cast<const float4*>(g_bias + co); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+    if (g_addend) {
+      const float4 a = *reinterpret_cast<const float4*>(g_addend + (long long)m * p.ld_add + co);
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    if (g_mask) {
+      const float4 k = *reinterpret_cast<const float4*>(g_mask + (long long)m * p.ld_mask + co);
+      v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+    }
+    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<float4*>(g_out + (long long)m * p.ld_out + co) = v;
+  }
 }
 
 // ---- activation / gradient split: f32 [rows][ld] -> bf16 hi/lo planes with the same geometry ----
@@ -599,27 +642,33 @@ extern "C" int pp_conv_split_weights_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, 
   return PP_OK;
 }
 
-template <int TM, int TN>
-static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const void* alo, const void* whi, const void* wlo, int w_rows,
-                          int w_ld8, void* ohi, void* olo) {
-  constexpr int BM = 64 * TM, BN = 64 * TN;
-  p.n_tiles_n = (p.Nout + BN - 1) / BN;
-  const int n_tiles_m = (p.M + BM - 1) / BM;
-  const dim3 grid((unsigned)(n_tiles_m * p.n_tiles_n));
+static bool igemm3_fast_ok(const IgemmParams& p, bool planes, int w_rows, int w_ld8) {
   // the branch-free loop needs a tap-linear gather and 31-bit byte offsets (see igemm3f_kernel)
   static const bool fast_on = []() { const char* e = getenv("PP_CONV3_FAST"); return !(e && e[0] == '0'); }();
-  const long long a_bytes = p.src_rows * (long long)p.ld_src * (ahi ? 2 : 4);
+  const long long a_bytes = p.src_rows * (long long)p.ld_src * (planes ? 2 : 4);
   const long long w_bytes = (long long)p.kh * p.kw * w_rows * w_ld8 * 16;
   int max_sw = 0;
   for (int i = 0; i < p.n_seg; ++i) max_sw = p.seg[i].SW > max_sw ? p.seg[i].SW : max_sw;
-  const bool fast = fast_on && p.div == 1 && p.kh * p.kw <= 31 && a_bytes < (1ll << 31) && w_bytes < (1ll << 31) &&
-                    (long long)max_sw * p.ld_src * 4 < (1ll << 23) && p.src_rows > 0;
+  return fast_on && p.div == 1 && p.kh * p.kw <= 31 && a_bytes < (1ll << 31) && w_bytes < (1ll << 31) &&
+         (long long)max_sw * p.ld_src * 4 < (1ll << 23) && p.src_rows > 0;
+}
+
+template <int TM, int TN>
+static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const void* alo, const void* whi, const void* wlo, int w_rows,
+                          int w_ld8, void* ohi, void* olo, int splits, float* ws) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  p.n_tiles_n = (p.Nout + BN - 1) / BN;
+  const int n_tiles_m = (p.M + BM - 1) / BM;
+  const dim3 grid((unsigned)(n_tiles_m * p.n_tiles_n * splits));
+  const bool fast = igemm3_fast_ok(p, ahi != nullptr, w_rows, w_ld8);
+  const long long a_bytes = p.src_rows * (long long)p.ld_src * (ahi ? 2 : 4);
+  const long long w_bytes = (long long)p.kh * p.kw * w_rows * w_ld8 * 16;
   auto go = [&](auto ap, auto op) {
     constexpr bool AP = decltype(ap)::value, OP = decltype(op)::value;
     if (fast)
       hipLaunchKernelGGL((igemm3f_kernel<TM, TN, AP, OP>), grid, dim3(256), 0, st, p, AP ? ahi : (const void*)p.src, AP ? alo : nullptr,
                          (unsigned)a_bytes, whi, wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)ohi, (uint2*)olo,
-                         w_rows, w_ld8);
+                         w_rows, w_ld8, splits, ws);
     else
       hipLaunchKernelGGL((igemm3_kernel<TM, TN, AP, OP>), grid, dim3(256), 0, st, p, p.src, (const uint4*)(AP ? ahi : nullptr),
                          (const uint4*)(AP ? alo : nullptr), (const uint4*)whi, (const uint4*)wlo, p.bias, p.addend, p.mask_src, p.out,
@@ -631,22 +680,38 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
   else go(std::false_type{}, std::false_type{});
 }
 
-static void pick_tile3(const pp_ctx* ctx, int M, int Nout, int* tm, int* tn) {
+static void pick_tile3(const pp_ctx* ctx, int M, int Nout, int n_steps, bool may_split, int* tm, int* tn, int* splits) {
   // measured in-flight rates relative to 128x128 (tools/conv_bench.py): the LDS store path (ds_write_b128 of the
-  // staged tiles) costs ~30 % of the loop, so the tile with the fewest staged bytes per MFMA wins when it fills the chip
+  // staged tiles) costs ~30 % of the loop, so the tile with the fewest staged bytes per MFMA wins when it fills the chip.
+  // A workgroup costs (its k-steps + ~8 steps' worth of prologue, epilogue and launch ramp) x tile area; splitting the
+  // reduction S ways multiplies the workgroups and pays S x the output in f32 atomics plus the finishing pass.
   static const int cand[5][2] = {{4, 2}, {2, 2}, {1, 2}, {2, 1}, {1, 1}};
   static const double eff[5] = {1.1, 1.0, 0.9, 0.9, 0.8};
   static const int slots[5] = {2, 3, 4, 4, 4};
+  static const int split_cand[8] = {1, 2, 3, 4, 6, 8, 12, 16};
   const int cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
   double best = 1e300;
+  *splits = 1;
   for (int i = 0; i < 5; ++i) {
     const int bm = 64 * cand[i][0], bn = 64 * cand[i][1];
     const long long blocks = (long long)((M + bm - 1) / bm) * ((Nout + bn - 1) / bn);
-    const double t = est_rounds(blocks, slots[i], cus) * cand[i][0] * cand[i][1] / eff[i];
-    if (t < best * 0.999) {
-      best = t;
-      *tm = cand[i][0];
-      *tn = cand[i][1];
+    for (int si = 0; si < (may_split ? 8 : 1); ++si) {
+      const int sp = split_cand[si];
+      if (sp > 1 && n_steps / sp < 8) break;
+      const double steps = (double)((n_steps + sp - 1) / sp) + 8.0;
+      double t = est_rounds(blocks * sp, slots[i], cus) * steps * cand[i][0] * cand[i][1] / eff[i];
+      if (sp > 1) {
+        // atomics: sp x M x N x 4 B at ~1.3 TB/s; finish: ~12 B per output at ~4 TB/s + a launch; one k-step of a
+        // 128x128 tile ~ 2.1 us when the chip is full  ->  convert microseconds to the same step units
+        const double us = (double)M * Nout * 4.0 * sp / 1.3e6 + (double)M * Nout * 12.0 / 4.0e6 + 4.0;
+        t += us / 2.1 * 4.0;
+      }
+      if (t < best * 0.97) {
+        best = t;
+        *tm = cand[i][0];
+        *tn = cand[i][1];
+        *splits = sp;
+      }
     }
   }
   const char* e = getenv("PP_CONV3_TILE");
@@ -654,17 +719,33 @@ static void pick_tile3(const pp_ctx* ctx, int M, int Nout, int* tm, int* tn) {
     *tm = e[0] - '0';
     *tn = e[2] - '0';
   }
+  if (const char* es = getenv("PP_CONV3_SPLITS")) {
+    const int v = atoi(es);
+    if (v >= 1 && (v == 1 || (may_split && n_steps / v >= 1))) *splits = v;
+  }
 }
 
 static void dispatch3(pp_ctx* ctx, IgemmParams& p, const void* ahi, const void* alo, const void* whi, const void* wlo, int w_rows,
                       int w_ld8, void* ohi, void* olo) {
-  int tm, tn;
-  pick_tile3(ctx, p.M, p.Nout, &tm, &tn);
-  if (tm == 4) launch_igemm3<4, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo);
-  else if (tm == 2 && tn == 2) launch_igemm3<2, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo);
-  else if (tm == 1 && tn == 2) launch_igemm3<1, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo);
-  else if (tm == 2 && tn == 1) launch_igemm3<2, 1>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo);
-  else launch_igemm3<1, 1>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo);
+  int tm, tn, splits;
+  const int n_steps = p.kh * p.kw * (p.Cred / 32);
+  const bool may_split = ctx->ws != nullptr && !ohi && p.out != nullptr && (size_t)p.M * p.ld_out * 4 <= ctx->ws_bytes &&
+                         igemm3_fast_ok(p, ahi != nullptr, w_rows, w_ld8);
+  pick_tile3(ctx, p.M, p.Nout, n_steps, may_split, &tm, &tn, &splits);
+  if (getenv("PP_CONV_DEBUG")) fprintf(stderr, "igemm3 M %d N %d steps %d -> tile %dx%d splits %d\n", p.M, p.Nout, n_steps, 64 * tm, 64 * tn, splits);
+  float* ws = splits > 1 ? ctx->ws : nullptr;
+  if (tm == 4) launch_igemm3<4, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws);
+  else if (tm == 2 && tn == 2) launch_igemm3<2, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws);
+  else if (tm == 1 && tn == 2) launch_igemm3<1, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws);
+  else if (tm == 2 && tn == 1) launch_igemm3<2, 1>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws);
+  else launch_igemm3<1, 1>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws);
+  if (splits > 1) {
+    const long long total = (long long)p.M * ((p.Nout + 3) >> 2);
+    long long blocks = (total + 255) / 256;
+    const long long cap = (long long)(ctx->n_cu > 0 ? ctx->n_cu : 256) * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p, ctx->ws, p.bias, p.addend, p.mask_src, p.out);
+  }
 }
 
 extern "C" int pp_conv2d_nhwc_fwd_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const void* x_hi, const void* x_lo,

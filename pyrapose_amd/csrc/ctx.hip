@@ -37,6 +37,14 @@ extern "C" int pp_ctx_set_stream(pp_ctx* ctx, void* hip_stream) {
   return PP_OK;
 }
 
+extern "C" int pp_ctx_set_workspace(pp_ctx* ctx, void* zeroed, size_t bytes) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, (zeroed == nullptr) == (bytes == 0) && pp_is_aligned16(zeroed), PP_ERR_ARG, "pp_ctx_set_workspace: bad buffer");
+  ctx->ws = (float*)zeroed;
+  ctx->ws_bytes = bytes;
+  return PP_OK;
+}
+
 extern "C" const char* pp_last_error_string(pp_ctx* ctx) { return ctx ? ctx->err : "no context"; }
 
 extern "C" int pp_device_info(pp_ctx* ctx, int* n_cu, char* name, int name_len) {

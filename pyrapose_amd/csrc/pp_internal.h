@@ -13,6 +13,8 @@ struct pp_ctx {
   int n_cu;
   char name[128];
   char err[512];
+  float* ws;        // caller-provided scratch for split-K partial sums: all zeros between launches
+  size_t ws_bytes;
 };
 
 static inline int pp_fail(pp_ctx* ctx, int code, const char* fmt, ...) {

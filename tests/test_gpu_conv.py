@@ -393,3 +393,48 @@ def test_split_weights_batch_matches_per_tensor(ctx):
             assert (ta is None) == (tb is None)
             if ta is not None:
                 assert torch.equal(ta, tb)
+
+
+@pytest.mark.parametrize("splits", [2, 5])
+def test_conv_bf16x3_split_k(ctx, splits, monkeypatch):
+    """Split-K (pp_ctx_set_workspace): same result as the single-pass launch up to f32 summation order, both directions,
+    fused bias / residual / mask / ReLU applied by the finishing pass, workspace left all-zero."""
+    from pyrapose_amd import ops
+    rng = np.random.default_rng(11)
+    B, H, W, cin, cout, k = 2, 9, 13, 128, 80, 3
+    ld_y = 96
+    d = ops.make_conv_desc(B, [(H, W)], [(H, W)], cin, cout, k, 1, 1, 1, cin, ld_y, 80)
+    rows = B * H * W
+    x = torch.as_tensor(rng.standard_normal((rows, cin)), dtype=torch.float32).cuda()
+    w = torch.as_tensor(rng.standard_normal((k * k * cin, 80)) * 0.05, dtype=torch.float32).cuda()
+    bias = torch.as_tensor(rng.standard_normal((80,)), dtype=torch.float32).cuda()
+    res = torch.as_tensor(rng.standard_normal((rows, ld_y)), dtype=torch.float32).cuda()
+    i16 = dict(dtype=torch.int16, device="cuda")
+    fh, fl = torch.zeros((k * k, cout, cin), **i16), torch.zeros((k * k, cout, cin), **i16)
+    dh, dl = torch.zeros((k * k, cin, ld_y), **i16), torch.zeros((k * k, cin, ld_y), **i16)
+    ops.conv_split_weights3(ctx, d, w, fh, fl, dh, dl)
+    gy = torch.zeros((rows, ld_y), dtype=torch.float32, device="cuda")
+    gy[:, :cout] = torch.as_tensor(rng.standard_normal((rows, cout)), dtype=torch.float32).cuda()
+    add = torch.as_tensor(rng.standard_normal((rows, cin)), dtype=torch.float32).cuda()
+    msk = torch.as_tensor(rng.standard_normal((rows, cin)), dtype=torch.float32).cuda()
+
+    def run():
+        y = torch.full((rows, ld_y), float("nan"), dtype=torch.float32, device="cuda")
+        dx = torch.full((rows, cin), float("nan"), dtype=torch.float32, device="cuda")
+        ops.conv_fwd3(ctx, d, x, fh, fl, bias, res, True, y)
+        ops.conv_bwd_data3(ctx, d, gy, dh, dl, add, msk, dx)
+        torch.cuda.synchronize()
+        return y[:, :cout].clone(), dx.clone()
+
+    monkeypatch.setenv("PP_CONV3_SPLITS", "1")
+    y1, dx1 = run()
+    ctx.set_workspace(rows * max(ld_y, cin) * 4)
+    try:
+        monkeypatch.setenv("PP_CONV3_SPLITS", str(splits))
+        y2, dx2 = run()
+        assert float(ctx.workspace.abs().max()) == 0.0
+    finally:
+        ctx.set_workspace(0)
+    assert rel_err(y2.cpu().numpy(), y1.cpu().numpy()) < 2e-6
+    assert rel_err(dx2.cpu().numpy(), dx1.cpu().numpy()) < 2e-6
+    assert not torch.equal(y1, torch.zeros_like(y1))
