@@ -830,6 +830,7 @@ struct Wgrad3Params {
   int Cin, Cout;
   int kh, kw, stride, pad_t, pad_l;
   int k_tiles_per_tap, n_tiles_k, n_tiles_n, splits, rows_per_split;
+  int max_wraps;  // ceil(32 / narrowest level width): row wraps one 32-row step can cross
   long long src_rows;
 };
 
@@ -1161,30 +1162,41 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
 #pragma unroll
   for (int j = 0; j < BN / 32; ++j) bsum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool do_bias = (g_dbias != nullptr) && (tile_k == 0);
-  const float bmask = do_bias ? 1.f : 0.f;
+  // Per-thread walk over its pixel rows m = m_begin + prow + 32 * step: (image base, y, x) advance incrementally
+  // (x += 32 with a bounded number of row wraps; wraps = ceil(32 / narrowest level)); only when a lane crosses into
+  // the next pyramid level does the wave take the (wave-uniform, rare) full decode.
   int m_cur = m_begin + prow;
-
-  auto load_step = [&]() {
-    const int m = m_cur;
-    int rbeg = p.seg[0].row_begin, sb = p.seg[0].src_row_begin, OH = p.seg[0].OH, OW = p.seg[0].OW, SH = p.seg[0].SH, SW = p.seg[0].SW;
+  int c_OW, c_OH, c_SW, c_SH, c_end, r_x, r_y, r_img;  // level constants and position of row m_cur
+  auto decode = [&](int m) {
+    int rbeg = p.seg[0].row_begin, sb = p.seg[0].src_row_begin;
+    c_OH = p.seg[0].OH; c_OW = p.seg[0].OW; c_SH = p.seg[0].SH; c_SW = p.seg[0].SW;
+    c_end = p.n_seg > 1 ? p.seg[1].row_begin : 0x7fffffff;
     for (int s = 1; s < p.n_seg; ++s) {
       const bool in = m >= p.seg[s].row_begin;
       rbeg = in ? p.seg[s].row_begin : rbeg;
       sb = in ? p.seg[s].src_row_begin : sb;
-      OH = in ? p.seg[s].OH : OH;
-      OW = in ? p.seg[s].OW : OW;
-      SH = in ? p.seg[s].SH : SH;
-      SW = in ? p.seg[s].SW : SW;
+      c_OH = in ? p.seg[s].OH : c_OH;
+      c_OW = in ? p.seg[s].OW : c_OW;
+      c_SH = in ? p.seg[s].SH : c_SH;
+      c_SW = in ? p.seg[s].SW : c_SW;
+      c_end = in ? ((s + 1 < p.n_seg) ? p.seg[s + 1].row_begin : 0x7fffffff) : c_end;
     }
-    const bool in_rng = m < m_end;
-    const int local = in_rng ? m - rbeg : 0;
-    const int hw = OH * OW;
-    int rem, x;
+    const int local = m < p.M ? m - rbeg : 0;
+    const int hw = c_OH * c_OW;
+    int rem;
     const int n = div_small(local, hw, __frcp_rn((float)hw), &rem);
-    const int y = div_small(rem, OW, __frcp_rn((float)OW), &x);
-    const int sy = y * p.stride + ty - p.pad_t, sx = x * p.stride + tx - p.pad_l;
-    const bool ok = in_rng && ((unsigned)sy < (unsigned)SH) && ((unsigned)sx < (unsigned)SW);
-    int xo = ((sb + n * SH * SW + sy * SW + sx) * p.ld_src + ci0) * ES + 16 * q8;
+    r_y = div_small(rem, c_OW, __frcp_rn((float)c_OW), &r_x);
+    r_img = sb + n * c_SH * c_SW;
+  };
+  decode(m_cur);
+  const int n_wraps = p.max_wraps;
+
+  auto load_step = [&]() {
+    const int m = m_cur;
+    const bool in_rng = m < m_end;
+    const int sy = r_y * p.stride + ty - p.pad_t, sx = r_x * p.stride + tx - p.pad_l;
+    const bool ok = in_rng && ((unsigned)sy < (unsigned)c_SH) && ((unsigned)sx < (unsigned)c_SW);
+    int xo = ((r_img + sy * c_SW + sx) * p.ld_src + ci0) * ES + 16 * q8;
     xo = ok ? xo : PP_BUF_OOB;
 #pragma unroll
     for (int j = 0; j < QA; ++j) {
@@ -1199,14 +1211,32 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
       rb[j] = buf_load16(rs_d0, o, 128 * j);
       if (AP) rbl[j] = buf_load16(rs_d1, o, 128 * j);
     }
+  };
+  auto next_row = [&]() {  // m_cur += 32
     m_cur += BK;
+    if (__builtin_amdgcn_ballot_w64(m_cur >= c_end) != 0) {
+      decode(m_cur);
+    } else {
+      r_x += BK;
+      for (int i = 0; i < n_wraps; ++i) {
+        const bool w = r_x >= c_OW;
+        r_x -= w ? c_OW : 0;
+        r_y += w ? 1 : 0;
+      }
+      const bool wy = r_y >= c_OH;  // (32 consecutive cells never span more than one image boundary: OH * OW >= 32 is host-checked)
+      r_y -= wy ? c_OH : 0;
+      r_img += wy ? c_SH * c_SW : 0;
+    }
   };
   auto bf2f = [](unsigned int packed, float* lo_elem, float* hi_elem) {
     *lo_elem = __uint_as_float(packed << 16);
     *hi_elem = __uint_as_float(packed & 0xffff0000u);
   };
-  auto split_step = [&]() {  // conversion (f32 path) and the bias partial sums: VALU only, issued under the MFMAs
+  auto split_step = [&](auto with_bias) {  // conversion (f32 path) and the bias partial sums: VALU only, under the MFMAs
+    constexpr bool WB = decltype(with_bias)::value;
+    const float bmask = 1.f;
     if (AP) {
+      if (!WB) return;
 #pragma unroll
       for (int j = 0; j < QB; ++j) {  // dy = hi + lo (2^-17)
         const unsigned int hw4[4] = {rb[j].x, rb[j].y, rb[j].z, rb[j].w}, lw4[4] = {rbl[j].x, rbl[j].y, rbl[j].z, rbl[j].w};
@@ -1231,8 +1261,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
       for (int j = 0; j < QB; ++j) {
         const float4 v = *reinterpret_cast<const float4*>(&rb[j]);
         split4(v, &sbh[j], &sbl[j]);
-        bsum[j].x = fmaf(v.x, bmask, bsum[j].x); bsum[j].y = fmaf(v.y, bmask, bsum[j].y);
-        bsum[j].z = fmaf(v.z, bmask, bsum[j].z); bsum[j].w = fmaf(v.w, bmask, bsum[j].w);
+        if (WB) { bsum[j].x += v.x; bsum[j].y += v.y; bsum[j].z += v.z; bsum[j].w += v.w; }
       }
     }
   };
@@ -1274,44 +1303,49 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
   const int cbase = 16 * (grp & 1), hh = grp >> 1;
   const int il = lane & 31, h = lane >> 5;
 
-  load_step();  // (n_steps == 0: every row is out of range -> zeros)
-  split_step();
-  store_step();
-  __syncthreads();
-  for (int step = 0; step < n_steps; ++step) {
-    load_step();  // past the last step m >= m_end: zeros, never stored
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < BK / 16; ++s) {
-      const int row0 = 16 * s + 8 * hh + gq;  // pixel row this lane addresses in the first transposed read
-      bf16x8 xh[TM], xl[TM], gh[TN], gl[TN];
-#pragma unroll
-      for (int a = 0; a < TM; ++a) {
-        const int col = wm * 32 * TM + a * 32 + cbase + 4 * gp;
-        xh[a] = tr_frag(Xhi, row0 * PA + col, (row0 + 4) * PA + col);
-        xl[a] = tr_frag(Xlo, row0 * PA + col, (row0 + 4) * PA + col);
-      }
-#pragma unroll
-      for (int c = 0; c < TN; ++c) {
-        const int col = wn * 32 * TN + c * 32 + cbase + 4 * gp;
-        gh[c] = tr_frag(Ghi, row0 * PB + col, (row0 + 4) * PB + col);
-        gl[c] = tr_frag(Glo, row0 * PB + col, (row0 + 4) * PB + col);
-      }
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int c = 0; c < TN; ++c) {
-          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[a], gh[c], acc[a][c], 0, 0, 0);
-          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[a], gl[c], acc[a][c], 0, 0, 0);
-          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[a], gh[c], acc[a][c], 0, 0, 0);
-        }
-      if (s == 0) __builtin_amdgcn_sched_barrier(0);
-    }
-    split_step();
-    __syncthreads();
+  auto k_loop = [&](auto with_bias) {
+    load_step();  // (n_steps == 0: every row is out of range -> zeros)
+    split_step(with_bias);
     store_step();
     __syncthreads();
-  }
+    for (int step = 0; step < n_steps; ++step) {
+      next_row();
+      load_step();  // past the last step m >= m_end: zeros, never stored
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < BK / 16; ++s) {
+        const int row0 = 16 * s + 8 * hh + gq;  // pixel row this lane addresses in the first transposed read
+        bf16x8 xh[TM], xl[TM], gh[TN], gl[TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+          const int col = wm * 32 * TM + a * 32 + cbase + 4 * gp;
+          xh[a] = tr_frag(Xhi, row0 * PA + col, (row0 + 4) * PA + col);
+          xl[a] = tr_frag(Xlo, row0 * PA + col, (row0 + 4) * PA + col);
+        }
+#pragma unroll
+        for (int c = 0; c < TN; ++c) {
+          const int col = wn * 32 * TN + c * 32 + cbase + 4 * gp;
+          gh[c] = tr_frag(Ghi, row0 * PB + col, (row0 + 4) * PB + col);
+          gl[c] = tr_frag(Glo, row0 * PB + col, (row0 + 4) * PB + col);
+        }
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int c = 0; c < TN; ++c) {
+            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[a], gh[c], acc[a][c], 0, 0, 0);
+            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[a], gl[c], acc[a][c], 0, 0, 0);
+            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[a], gh[c], acc[a][c], 0, 0, 0);
+          }
+        if (s == 0) __builtin_amdgcn_sched_barrier(0);
+      }
+      split_step(with_bias);
+      __syncthreads();
+      store_step();
+      __syncthreads();
+    }
+  };
+  if (do_bias) k_loop(std::true_type{});
+  else k_loop(std::false_type{});
 
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
@@ -1365,7 +1399,13 @@ static void launch_wgrad3(pp_ctx* ctx, Wgrad3Params& p, const float* x, const fl
   static const bool fast_on = []() { const char* e = getenv("PP_CONV3_FAST"); return !(e && e[0] == '0'); }();
   const int es = xhi ? 2 : 4;
   const long long x_bytes = p.src_rows * (long long)p.ld_src * es, d_bytes = (long long)p.M * p.ld_dy * es;
-  const bool fast = fast_on && x_bytes < (1ll << 31) && d_bytes < (1ll << 31) && p.M < (1 << 24) && p.src_rows > 0;
+  int min_ow = 1 << 30, min_hw = 1 << 30;
+  for (int i = 0; i < p.n_seg; ++i) {
+    min_ow = p.seg[i].OW < min_ow ? p.seg[i].OW : min_ow;
+    min_hw = p.seg[i].OH * p.seg[i].OW < min_hw ? p.seg[i].OH * p.seg[i].OW : min_hw;
+  }
+  p.max_wraps = (32 + min_ow - 1) / min_ow;
+  const bool fast = fast_on && x_bytes < (1ll << 31) && d_bytes < (1ll << 31) && p.M < (1 << 24) && p.src_rows > 0 && min_hw >= 32;
   const int slots = fast ? ((TM * TN == 4) ? 3 : 4) : ((TM * TN == 4) ? 2 : 3);
   const double tile_work = (double)(TM * TN) / 4.0;
   const double atomic_us_per_split = (double)tiles * BM * BN * 4.0 / 1.3e6;

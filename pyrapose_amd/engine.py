@@ -300,7 +300,8 @@ class Engine(object):
         return y
 
     def _wants_planes(self, s):
-        return self.train and s.trainable and s.cin % 64 == 0
+        # worth it only where the weight-gradient launch is big and conversion-bound: the wide 3x3 convs (regression head)
+        return self.train and s.trainable and s.cin % 64 == 0 and s.k == 3 and s.cin >= int(_os.environ.get("PP_PLANES_MIN_CIN", "512"))
 
     def _build_forward(self):
         B, H, W = self.B, self.H, self.W
