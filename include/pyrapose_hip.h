@@ -40,11 +40,11 @@ typedef struct pp_ctx pp_ctx;
 int pp_ctx_create(pp_ctx** out, int device, void* hip_stream);
 void pp_ctx_destroy(pp_ctx* ctx);
 int pp_ctx_set_stream(pp_ctx* ctx, void* hip_stream);
-/* Optional scratch for the bf16x3 convolutions: a device buffer the caller has ZEROED.  With it, launches whose output
- * tiles cannot fill the chip split their reduction over several workgroups (partial sums by f32 atomics into the
- * scratch, then a finishing pass that applies bias / residual / mask / ReLU and re-zeroes what it read), so the
- * buffer is all zeros again after every call.  One buffer per context (= per stream); NULL, 0 removes it. */
-int pp_ctx_set_workspace(pp_ctx* ctx, void* zeroed_device_buffer, size_t bytes);
+/* Optional scratch for the bf16x3 convolutions (any contents).  With it, launches whose output tiles cannot fill the
+ * chip split their reduction over S workgroups per tile: each writes its partial sums to slice s of the scratch and a
+ * finishing pass adds the slices in a fixed order and applies bias / residual / mask / ReLU (deterministic, no
+ * atomics).  A launch uses S * rows * ld_out * 4 bytes.  One buffer per context (= per stream); NULL, 0 removes it. */
+int pp_ctx_set_workspace(pp_ctx* ctx, void* device_buffer, size_t bytes);
 const char* pp_last_error_string(pp_ctx* ctx);
 const char* pp_version(void);
 /* number of compute units / name of the device the ctx is bound to (for bench metadata) */

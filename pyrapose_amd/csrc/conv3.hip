@@ -494,7 +494,9 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
     store_step();
     __syncthreads();
   }
-  if (splits > 1) {  // partial sums only: splitk_finish_kernel applies the epilogue once every split has landed
+  if (splits > 1) {  // partial sums only (slice `split` of the scratch): splitk_finish_kernel sums the slices in a fixed
+                     // order and applies the epilogue -> deterministic, no atomics, nothing to zero
+    float* slice = g_ws + (long long)split * p.M * p.ld_out;
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
           const int co = n0 + wn * 32 * TN + b * 32 + il;
-          if (m < p.M && co < p.Nout) unsafeAtomicAdd(g_ws + (long long)m * p.ld_out + co, acc[a][b][r]);
+          if (m < p.M && co < ((p.Nout + 3) & ~3)) slice[(long long)m * p.ld_out + co] = acc[a][b][r];
         }
       }
     return;
@@ -511,16 +513,19 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
   epilogue3<TM, TN, OP, 4>(p, acc, smem, m0, n0, tid, wm, wn, il, h, g_bias, g_addend, g_mask, g_out, g_ohi, g_olo);
 }
 
-// out = relu?(mask?(ws + bias + addend)) over [M][ceil4(Nout)], and ws := 0 again (the workspace invariant)
-__global__ void splitk_finish_kernel(const IgemmParams p, float* __restrict__ ws, const float* __restrict__ g_bias,
+// out = relu?(mask?(sum_s ws[s] + bias + addend)) over [M][ceil4(Nout)]
+__global__ void splitk_finish_kernel(const IgemmParams p, int splits, const float* __restrict__ ws, const float* __restrict__ g_bias,
                                      const float* __restrict__ g_addend, const float* __restrict__ g_mask, float* __restrict__ g_out) {
   const int n4 = (p.Nout + 3) >> 2;
-  const long long total = (long long)p.M * n4;
+  const long long total = (long long)p.M * n4, slice = (long long)p.M * p.ld_out;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int m = (int)(i / n4), co = 4 * (int)(i - (long long)m * n4);
-    float4* w4 = reinterpret_cast<float4*>(ws + (long long)m * p.ld_out + co);
-    float4 v = *w4;
-    *w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* w = ws + (long long)m * p.ld_out + co;
+    float4 v = *reinterpret_cast<const float4*>(w);
+    for (int s = 1; s < splits; ++s) {
+      const float4 q = *reinterpret_cast<const float4*>(w + s * slice);
+      v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
     if (g_bias) { const float4 b = *reinterpret_cast<const float4*>(g_bias + co); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
     if (g_addend) {
       const float4 a = *reinterpret_cast<const float4*>(g_addend + (long long)m * p.ld_add + co);
@@ -680,7 +685,7 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
   else go(std::false_type{}, std::false_type{});
 }
 
-static void pick_tile3(const pp_ctx* ctx, int M, int Nout, int n_steps, bool may_split, int* tm, int* tn, int* splits) {
+static void pick_tile3(const pp_ctx* ctx, int M, int Nout, int ld_out, int n_steps, bool may_split, int* tm, int* tn, int* splits) {
   // measured in-flight rates relative to 128x128 (tools/conv_bench.py): the LDS store path (ds_write_b128 of the
   // staged tiles) costs ~30 % of the loop, so the tile with the fewest staged bytes per MFMA wins when it fills the chip.
   // A workgroup costs (its k-steps + ~8 steps' worth of prologue, epilogue and launch ramp) x tile area; splitting the
@@ -690,6 +695,7 @@ static void pick_tile3(const pp_ctx* ctx, int M, int Nout, int n_steps, bool may
   static const int slots[5] = {2, 3, 4, 4, 4};
   static const int split_cand[8] = {1, 2, 3, 4, 6, 8, 12, 16};
   const int cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
+  const long long ws_bytes = (long long)ctx->ws_bytes;
   double best = 1e300;
   *splits = 1;
   for (int i = 0; i < 5; ++i) {
@@ -697,13 +703,13 @@ static void pick_tile3(const pp_ctx* ctx, int M, int Nout, int n_steps, bool may
     const long long blocks = (long long)((M + bm - 1) / bm) * ((Nout + bn - 1) / bn);
     for (int si = 0; si < (may_split ? 8 : 1); ++si) {
       const int sp = split_cand[si];
-      if (sp > 1 && n_steps / sp < 8) break;
+      if (sp > 1 && (n_steps / sp < 8 || (long long)sp * M * ld_out * 4 > ws_bytes)) break;
       const double steps = (double)((n_steps + sp - 1) / sp) + 8.0;
       double t = est_rounds(blocks * sp, slots[i], cus) * steps * cand[i][0] * cand[i][1] / eff[i];
       if (sp > 1) {
-        // atomics: sp x M x N x 4 B at ~1.3 TB/s; finish: ~12 B per output at ~4 TB/s + a launch; one k-step of a
-        // 128x128 tile ~ 2.1 us when the chip is full  ->  convert microseconds to the same step units
-        const double us = (double)M * Nout * 4.0 * sp / 1.3e6 + (double)M * Nout * 12.0 / 4.0e6 + 4.0;
+        // slices: sp x M x N x 4 B written and read back (~4 TB/s), the epilogue operands, one more launch; one k-step
+        // of a 128x128 tile ~ 2.1 us when the chip is full  ->  convert microseconds to the same step units
+        const double us = (double)M * Nout * (8.0 * sp + 12.0) / 4.0e6 + 4.0;
         t += us / 2.1 * 4.0;
       }
       if (t < best * 0.97) {
@@ -721,7 +727,7 @@ static void pick_tile3(const pp_ctx* ctx, int M, int Nout, int n_steps, bool may
   }
   if (const char* es = getenv("PP_CONV3_SPLITS")) {
     const int v = atoi(es);
-    if (v >= 1 && (v == 1 || (may_split && n_steps / v >= 1))) *splits = v;
+    if (v >= 1 && (v == 1 || (may_split && n_steps / v >= 1 && (long long)v * M * ld_out * 4 <= ws_bytes))) *splits = v;
   }
 }
 
@@ -729,9 +735,8 @@ static void dispatch3(pp_ctx* ctx, IgemmParams& p, const void* ahi, const void* 
                       int w_ld8, void* ohi, void* olo) {
   int tm, tn, splits;
   const int n_steps = p.kh * p.kw * (p.Cred / 32);
-  const bool may_split = ctx->ws != nullptr && !ohi && p.out != nullptr && (size_t)p.M * p.ld_out * 4 <= ctx->ws_bytes &&
-                         igemm3_fast_ok(p, ahi != nullptr, w_rows, w_ld8);
-  pick_tile3(ctx, p.M, p.Nout, n_steps, may_split, &tm, &tn, &splits);
+  const bool may_split = ctx->ws != nullptr && !ohi && p.out != nullptr && igemm3_fast_ok(p, ahi != nullptr, w_rows, w_ld8);
+  pick_tile3(ctx, p.M, p.Nout, p.ld_out, n_steps, may_split, &tm, &tn, &splits);
   if (getenv("PP_CONV_DEBUG")) fprintf(stderr, "igemm3 M %d N %d steps %d -> tile %dx%d splits %d\n", p.M, p.Nout, n_steps, 64 * tm, 64 * tn, splits);
   float* ws = splits > 1 ? ctx->ws : nullptr;
   if (tm == 4) launch_igemm3<4, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws);
@@ -744,7 +749,8 @@ static void dispatch3(pp_ctx* ctx, IgemmParams& p, const void* ahi, const void* 
     long long blocks = (total + 255) / 256;
     const long long cap = (long long)(ctx->n_cu > 0 ? ctx->n_cu : 256) * 8;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p, ctx->ws, p.bias, p.addend, p.mask_src, p.out);
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p, splits, ctx->ws, p.bias, p.addend, p.mask_src,
+                       p.out);
   }
 }
 

@@ -13,7 +13,7 @@ struct pp_ctx {
   int n_cu;
   char name[128];
   char err[512];
-  float* ws;        // caller-provided scratch for split-K partial sums: all zeros between launches
+  float* ws;        // caller-provided scratch for split-K partial sums (slices)
   size_t ws_bytes;
 };
 

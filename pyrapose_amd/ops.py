@@ -38,8 +38,8 @@ class Context:
         check(lib.pp_ctx_set_stream(self.handle, C.c_void_p(stream.cuda_stream)), self.handle, "pp_ctx_set_stream")
 
     def set_workspace(self, nbytes):
-        """Zeroed scratch for split-K convolutions (pp_ctx_set_workspace); 0 removes it."""
-        self.workspace = torch.zeros((int(nbytes) // 4,), dtype=torch.float32, device="cuda:%d" % self.device) if nbytes else None
+        """Scratch for split-K convolutions (pp_ctx_set_workspace); 0 removes it."""
+        self.workspace = torch.empty((int(nbytes) // 4,), dtype=torch.float32, device="cuda:%d" % self.device) if nbytes else None
         check(lib.pp_ctx_set_workspace(self.handle, _ptr(self.workspace), (int(nbytes) // 4) * 4 if nbytes else 0), self.handle,
               "pp_ctx_set_workspace")
 

@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--mode", default="fwd,dgrad,wgrad")
     args = ap.parse_args()
     ctx = ops.Context(0)
+    if os.environ.get("PP_SPLITK_MB"):
+        ctx.set_workspace(int(os.environ["PP_SPLITK_MB"]) << 20)
     for name in args.shape.split(","):
         B, shapes, cin, cout, k, stride, pad = SHAPES[name]
         rows = sum(B * h * w for h, w in shapes)
