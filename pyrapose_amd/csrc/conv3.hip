@@ -1414,7 +1414,9 @@ static void launch_wgrad3(pp_ctx* ctx, Wgrad3Params& p, const float* x, const fl
   const bool fast = fast_on && x_bytes < (1ll << 31) && d_bytes < (1ll << 31) && p.M < (1 << 24) && p.src_rows > 0 && min_hw >= 32;
   const int slots = fast ? ((TM * TN == 4) ? 3 : 4) : ((TM * TN == 4) ? 2 : 3);
   const double tile_work = (double)(TM * TN) / 4.0;
-  const double atomic_us_per_split = (double)tiles * BM * BN * 4.0 / 1.3e6;
+  // f32 atomics of one split's tiles at ~1.3 TB/s, half of it hidden under the k-loops of other workgroups (measured:
+  // 256-channel head convs 252 -> 234 us going from 14 to 21 splits, i.e. from 2 to 3 workgroups per CU)
+  const double atomic_us_per_split = 0.5 * (double)tiles * BM * BN * 4.0 / 1.3e6;
   int splits = 1;
   double best = 1e300;
   for (int sp = 1; sp <= max_splits; ++sp) {
