@@ -45,8 +45,22 @@ __device__ __forceinline__ void split4(const float4& v4, uint2* out_hi, uint2* o
   *out_lo = *reinterpret_cast<uint2*>(&l);
 }
 
+// exact a / b for 0 <= a < 2^24, b >= 1 by one reciprocal multiply and a +-1 correction
+__device__ __forceinline__ int div_small(int a, int b, float rcp_b, int* rem) {
+  int q = (int)((float)a * rcp_b);
+  int r = a - q * b;
+  const bool lo = r < 0;
+  q -= lo ? 1 : 0;
+  r += lo ? b : 0;
+  const bool hi = r >= b;
+  q += hi ? 1 : 0;
+  r -= hi ? b : 0;
+  *rem = r;
+  return q;
+}
+
 // ---- epilogue through LDS (see conv.hip), shared by both main loops ----
-template <int TM, int TN, bool OP, int GOP = 1>
+template <int TM, int TN, bool OP, int GOP = 1, bool SC = false>
 __device__ __forceinline__ void epilogue3(const IgemmParams& p, floatx16 (&acc)[TM][TN], uint4* smem, int m0, int n0, int tid, int wm,
                                           int wn, int il, int h, const float* __restrict__ g_bias,
                                           const float* __restrict__ g_addend, const float* __restrict__ g_mask,
@@ -90,11 +104,20 @@ __device__ __forceinline__ void epilogue3(const IgemmParams& p, floatx16 (&acc)[
 #pragma unroll
           for (int s0 = 0; s0 < SWEEPS; s0 += G) {
             float4 ad[G], mk[G];
+            int mo[G];  // row of the output / addend / mask tensors (SC: the class row scattered into the full grid)
 #pragma unroll
             for (int g = 0; g < G; ++g) {
               const int m = min(base_row + e_r + RPI * (s0 + g), m_last);
-              if (has_add) ad[g] = *reinterpret_cast<const float4*>(g_addend + (long long)m * p.ld_add + co);
-              if (has_mask) mk[g] = *reinterpret_cast<const float4*>(g_mask + (long long)m * p.ld_mask + co);
+              mo[g] = m;
+              if (SC) {
+                const int hw = p.seg[0].OH * p.seg[0].OW;
+                int rem, xq;
+                const int n = div_small(m, hw, __frcp_rn((float)hw), &rem);
+                const int yq = div_small(rem, p.seg[0].OW, __frcp_rn((float)p.seg[0].OW), &xq);
+                mo[g] = (n * p.sc_H + 2 * yq + p.sc_cy) * p.sc_W + 2 * xq + p.sc_cx;
+              }
+              if (has_add) ad[g] = *reinterpret_cast<const float4*>(g_addend + (long long)mo[g] * p.ld_add + co);
+              if (has_mask) mk[g] = *reinterpret_cast<const float4*>(g_mask + (long long)mo[g] * p.ld_mask + co);
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
@@ -109,11 +132,11 @@ __device__ __forceinline__ void epilogue3(const IgemmParams& p, floatx16 (&acc)[
               }
               if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
               if (m <= m_last) {
-                if (!OP || g_out != nullptr) *reinterpret_cast<float4*>(g_out + (long long)m * p.ld_out + co) = v;
+                if (!OP || g_out != nullptr) *reinterpret_cast<float4*>(g_out + (long long)mo[g] * p.ld_out + co) = v;
                 if (OP) {  // the consumer convs read their operand pre-split: split once here instead of per tile
                   uint2 oh, ol;
                   split4(v, &oh, &ol);
-                  const long long o4 = ((long long)m * p.ld_out + co) >> 2;
+                  const long long o4 = ((long long)mo[g] * p.ld_out + co) >> 2;
                   g_ohi[o4] = oh;
                   g_olo[o4] = ol;
                 }
@@ -316,7 +339,7 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, int voff, 
 
 // Measured and NOT kept: the same loop on v_mfma_f32_16x16x32_bf16 (48 instead of 24 MFMAs per step, lane = (row, octet)
 // staging map, un-rotated image): bit-identical results, 20 % slower on every head shape (255-295 vs 325-355 TFLOP/s).
-template <int TM, int TN, bool AP, bool OP>
+template <int TM, int TN, bool AP, bool OP, bool SC = false>
 __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4)) void igemm3f_kernel(
     const IgemmParams p, const void* __restrict__ g_a0, const void* __restrict__ g_a1, unsigned a_bytes,
     const void* __restrict__ g_whi, const void* __restrict__ g_wlo, unsigned w_bytes,
@@ -396,7 +419,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
         ra[i][1] = *reinterpret_cast<const float4*>(&q1);
       }
     }
-    const int b_uni = tap * b_tap + (red0 >> 3) * 16;
+    const int b_uni = ((p.w_ty0 + p.w_tstep * ty) * p.w_kw + p.w_tx0 + p.w_tstep * tx) * b_tap + (red0 >> 3) * 16;
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
       rbh[i] = buf_load16(rs_wh, b_base[i], b_uni);
@@ -510,7 +533,27 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
       }
     return;
   }
-  epilogue3<TM, TN, OP, 4>(p, acc, smem, m0, n0, tid, wm, wn, il, h, g_bias, g_addend, g_mask, g_out, g_ohi, g_olo);
+  epilogue3<TM, TN, OP, 4, SC>(p, acc, smem, m0, n0, tid, wm, wn, il, h, g_bias, g_addend, g_mask, g_out, g_ohi, g_olo);
+}
+
+// parity class without taps (e.g. the odd cells of a 1x1 stride-2 conv): dx = mask?(addend or 0) at the class rows
+__global__ void class_fill_kernel(const IgemmParams p, const float* __restrict__ g_addend, const float* __restrict__ g_mask,
+                                  float* __restrict__ g_out) {
+  const int n4 = (p.Nout + 3) >> 2;
+  const long long total = (long long)p.M * n4;
+  const int hw = p.seg[0].OH * p.seg[0].OW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / n4), co = 4 * (int)(i - (long long)m * n4);
+    const int n = m / hw, rem = m - n * hw, yq = rem / p.seg[0].OW, xq = rem - yq * p.seg[0].OW;
+    const long long mo = (long long)(n * p.sc_H + 2 * yq + p.sc_cy) * p.sc_W + 2 * xq + p.sc_cx;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g_addend) v = *reinterpret_cast<const float4*>(g_addend + mo * p.ld_add + co);
+    if (g_mask) {
+      const float4 k = *reinterpret_cast<const float4*>(g_mask + mo * p.ld_mask + co);
+      v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+    }
+    *reinterpret_cast<float4*>(g_out + mo * p.ld_out + co) = v;
+  }
 }
 
 // out = relu?(mask?(sum_s ws[s] + bias + addend)) over [M][ceil4(Nout)]
@@ -651,7 +694,7 @@ static bool igemm3_fast_ok(const IgemmParams& p, bool planes, int w_rows, int w_
   // the branch-free loop needs a tap-linear gather and 31-bit byte offsets (see igemm3f_kernel)
   static const bool fast_on = []() { const char* e = getenv("PP_CONV3_FAST"); return !(e && e[0] == '0'); }();
   const long long a_bytes = p.src_rows * (long long)p.ld_src * (planes ? 2 : 4);
-  const long long w_bytes = (long long)p.kh * p.kw * w_rows * w_ld8 * 16;
+  const long long w_bytes = (long long)p.w_taps * w_rows * w_ld8 * 16;
   int max_sw = 0;
   for (int i = 0; i < p.n_seg; ++i) max_sw = p.seg[i].SW > max_sw ? p.seg[i].SW : max_sw;
   return fast_on && p.div == 1 && p.kh * p.kw <= 31 && a_bytes < (1ll << 31) && w_bytes < (1ll << 31) &&
@@ -667,7 +710,12 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
   const dim3 grid((unsigned)(n_tiles_m * p.n_tiles_n * splits));
   const bool fast = igemm3_fast_ok(p, ahi != nullptr, w_rows, w_ld8);
   const long long a_bytes = p.src_rows * (long long)p.ld_src * (ahi ? 2 : 4);
-  const long long w_bytes = (long long)p.kh * p.kw * w_rows * w_ld8 * 16;
+  const long long w_bytes = (long long)p.w_taps * w_rows * w_ld8 * 16;
+  if (p.sc_on) {  // parity-class launch of a stride-2 bwd-data (host guarantees: fast, no planes, no split)
+    hipLaunchKernelGGL((igemm3f_kernel<TM, TN, false, false, true>), grid, dim3(256), 0, st, p, (const void*)p.src, nullptr, (unsigned)a_bytes, whi,
+                       wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)nullptr, (uint2*)nullptr, w_rows, w_ld8, 1, nullptr);
+    return;
+  }
   auto go = [&](auto ap, auto op) {
     constexpr bool AP = decltype(ap)::value, OP = decltype(op)::value;
     if (fast)
@@ -735,7 +783,7 @@ static void dispatch3(pp_ctx* ctx, IgemmParams& p, const void* ahi, const void* 
                       int w_ld8, void* ohi, void* olo) {
   int tm, tn, splits;
   const int n_steps = p.kh * p.kw * (p.Cred / 32);
-  const bool may_split = ctx->ws != nullptr && !ohi && p.out != nullptr && igemm3_fast_ok(p, ahi != nullptr, w_rows, w_ld8);
+  const bool may_split = ctx->ws != nullptr && !ohi && p.out != nullptr && !p.sc_on && igemm3_fast_ok(p, ahi != nullptr, w_rows, w_ld8);
   pick_tile3(ctx, p.M, p.Nout, p.ld_out, n_steps, may_split, &tm, &tn, &splits);
   if (getenv("PP_CONV_DEBUG")) fprintf(stderr, "igemm3 M %d N %d steps %d -> tile %dx%d splits %d\n", p.M, p.Nout, n_steps, 64 * tm, 64 * tn, splits);
   float* ws = splits > 1 ? ctx->ws : nullptr;
@@ -779,6 +827,7 @@ extern "C" int pp_conv2d_nhwc_fwd_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, con
   p.Cred = d->cin; p.Nout = d->cout; p.w_tap_rows = d->cin;
   p.kh = d->kh; p.kw = d->kw;
   p.mul = d->stride; p.tsign = 1; p.off_y = -d->pad_t; p.off_x = -d->pad_l; p.div = 1;
+  p.w_ty0 = 0; p.w_tx0 = 0; p.w_tstep = 1; p.w_kw = d->kw; p.w_taps = d->kh * d->kw;
   PP_CHECK_ARG(ctx, (y_hi == nullptr) == (y_lo == nullptr) && (!y_hi || (d->ld_y % 4 == 0 && pp_is_aligned16(y_hi) && pp_is_aligned16(y_lo))),
                PP_ERR_ARG, "pp_conv2d_nhwc_fwd_bf16x3: output planes");
   dispatch3(ctx, p, x_hi, x_lo, w_hi, w_lo, d->cout, d->cin / 8, y_hi, y_lo);
@@ -812,8 +861,54 @@ extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d
   p.Cred = cred; p.Nout = d->cin; p.w_tap_rows = d->cin;
   p.kh = d->kh; p.kw = d->kw;
   p.mul = 1; p.tsign = -1; p.off_y = d->pad_t; p.off_x = d->pad_l; p.div = d->stride;
+  p.w_ty0 = 0; p.w_tx0 = 0; p.w_tstep = 1; p.w_kw = d->kw; p.w_taps = d->kh * d->kw;
   PP_CHECK_ARG(ctx, (dx_hi == nullptr) == (dx_lo == nullptr) && (!dx_hi || (d->ld_x % 4 == 0 && pp_is_aligned16(dx_hi) && pp_is_aligned16(dx_lo))),
                PP_ERR_ARG, "pp_conv2d_nhwc_bwd_data_bf16x3: output planes");
+  static const bool s2_classes = []() { const char* e = getenv("PP_CONV3_S2CLASSES"); return !(e && e[0] == '0'); }();
+  if (d->stride == 2 && s2_classes && dy && dx && !dx_hi && d->in.n_seg == 1) {
+    // Stride-2 bwd-data as four stride-1 launches, one per parity class (cy, cx) of the input grid: input cell
+    // (2y'+cy, 2x'+cx) only receives the taps ty = ty0 + 2i with ty0 = (cy + pad_t) & 1 (x alike), from output cell
+    // y' + (cy + pad_t - ty0)/2 - i.  The single-launch form spends 3/4 of its MFMAs on taps that the divisibility
+    // mask zeroes; here every MFMA is useful and classes without taps (1x1 kernels) only run the epilogue.
+    IgemmParams q = p;
+    q.div = 1;
+    const int H = d->in.h[0], W = d->in.w[0];
+    bool ok = true;
+    IgemmParams cls[4];
+    for (int c = 0; c < 4 && ok; ++c) {
+      const int cy = c >> 1, cx = c & 1;
+      IgemmParams& r = cls[c];
+      r = q;
+      const int ty0 = (cy + d->pad_t) & 1, tx0 = (cx + d->pad_l) & 1;
+      r.kh = ty0 < d->kh ? (d->kh - ty0 + 1) / 2 : 0;
+      r.kw = tx0 < d->kw ? (d->kw - tx0 + 1) / 2 : 0;
+      r.off_y = (cy + d->pad_t - ty0) / 2;
+      r.off_x = (cx + d->pad_l - tx0) / 2;
+      r.w_ty0 = ty0; r.w_tx0 = tx0; r.w_tstep = 2; r.w_kw = d->kw;
+      if (r.kh == 0 || r.kw == 0) r.kh = r.kw = 0;  // no taps: class_fill_kernel below
+      r.seg[0].OH = (H - cy + 1) / 2;
+      r.seg[0].OW = (W - cx + 1) / 2;
+      r.M = d->in.n_img * r.seg[0].OH * r.seg[0].OW;
+      r.sc_on = 1; r.sc_H = H; r.sc_W = W; r.sc_cy = cy; r.sc_cx = cx;
+      if (r.M > 0 && r.kh > 0 && !(igemm3_fast_ok(r, false, d->cin, cred / 8) && r.M < (1 << 24))) ok = false;
+    }
+    if (ok) {
+      for (int c = 0; c < 4; ++c) {
+        if (cls[c].M <= 0) continue;
+        if (cls[c].kh > 0) {
+          dispatch3(ctx, cls[c], nullptr, nullptr, w_hi, w_lo, d->cin, cred / 8, nullptr, nullptr);
+        } else {
+          const long long total = (long long)cls[c].M * ((cls[c].Nout + 3) >> 2);
+          long long blocks = (total + 255) / 256;
+          const long long cap = (long long)(ctx->n_cu > 0 ? ctx->n_cu : 256) * 8;
+          if (blocks > cap) blocks = cap;
+          hipLaunchKernelGGL(class_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, cls[c], addend, relu_src, dx);
+        }
+      }
+      PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_data_bf16x3");
+      return PP_OK;
+    }
+  }
   dispatch3(ctx, p, dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8, dx_hi, dx_lo);
   PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_data_bf16x3");
   return PP_OK;
@@ -1109,18 +1204,6 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 2 : 3) void wgrad3_kernel(con
 // (exact for m < 2^24, host-checked) instead of the incremental walk with its data-dependent loops, addresses both
 // operands with 32-bit buffer offsets (out-of-range = zeros: padding taps, rows past the split, columns past ld_dy)
 // and converts the loaded tile while its MFMAs drain.  No 64-bit address registers -> 3 workgroups per CU at 128x128.
-__device__ __forceinline__ int div_small(int a, int b, float rcp_b, int* rem) {
-  int q = (int)((float)a * rcp_b);
-  int r = a - q * b;
-  const bool lo = r < 0;
-  q -= lo ? 1 : 0;
-  r += lo ? b : 0;
-  const bool hi = r >= b;
-  q += hi ? 1 : 0;
-  r -= hi ? b : 0;
-  *rem = r;
-  return q;
-}
 
 template <int TM, int TN, bool AP>
 __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(const Wgrad3Params p, const void* __restrict__ g_x0,

@@ -35,6 +35,11 @@ struct IgemmParams {
   int mul, tsign, off_y, off_x, div;  // src = (pos*mul + tap*tsign + off) / div
   int n_tiles_n;
   long long src_rows;  // rows of the gathered tensor (all segments)
+  // weight tap of loop tap (ty, tx) = (w_ty0 + w_tstep*ty) * w_kw + (w_tx0 + w_tstep*tx); identity: 0, 1, 0, kw
+  int w_ty0, w_tx0, w_tstep, w_kw, w_taps;  // w_taps: taps in the weight planes (kh * kw of the conv)
+  // stride-2 bwd-data by parity class: enumerated row (n, y', x') of the class grid seg[0].OH x OW is written to (and
+  // reads addend / mask at) row (n*sc_H + 2y' + sc_cy) * sc_W + 2x' + sc_cx of the full tensor
+  int sc_on, sc_H, sc_W, sc_cy, sc_cx;
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8, each with a private L2).

@@ -54,6 +54,7 @@ CASES = [
     ("down3x3s2_even", 2, [(12, 16)], 256, 256, 3, 2, "same", None),
     ("down3x3s2_odd", 1, [(17, 23)], 256, 256, 3, 2, "same", None),
     ("bneck1x1s2", 2, [(12, 16)], 256, 128, 1, 2, 0, None),
+    ("bneck1x1s2_odd", 1, [(9, 13)], 128, 64, 1, 2, 0, None),
     ("bneck3x3_zp1_c64", 2, [(9, 11)], 64, 64, 3, 1, 1, None),
     ("bneck1x1_c64_c256", 3, [(10, 6)], 64, 256, 1, 1, 0, None),
     ("ragged_rows", 1, [(5, 7)], 128, 192, 3, 1, "same", None),

@@ -33,6 +33,11 @@ SHAPES = {
     "r2t": (13, [(64, 64)], 512, 512, 3, 1, 1),    # 2 rounds + 8 %
     "occ4": (8, [(64, 64)], 512, 512, 3, 1, 1),
     "occ2": (4, [(64, 64)], 512, 512, 3, 1, 1),
+    "down3": (8, [(60, 80)], 256, 256, 3, 2, 0),    # fpn_down3: 3x3 stride 2 'same' (pad_t = pad_l = 0)
+    "down4": (8, [(30, 40)], 256, 256, 3, 2, 0),
+    "r5a1": (8, [(30, 40)], 1024, 2048, 1, 2, 0),   # res5a_branch1: 1x1 stride 2
+    "r4a1": (8, [(60, 80)], 512, 1024, 1, 2, 0),
+    "r4a2a": (8, [(60, 80)], 512, 256, 1, 2, 0),
     "occ1": (2, [(64, 64)], 512, 512, 3, 1, 1),
     "occ8": (16, [(64, 64)], 512, 512, 3, 1, 1),
     "big2": (16, [(64, 64)], 512, 512, 3, 1, 1),   # 256x128 tiles: 256*4 = 1024 workgroups = 2 per CU x 2 rounds
@@ -50,18 +55,20 @@ def main():
         ctx.set_workspace(int(os.environ["PP_SPLITK_MB"]) << 20)
     for name in args.shape.split(","):
         B, shapes, cin, cout, k, stride, pad = SHAPES[name]
-        rows = sum(B * h * w for h, w in shapes)
+        rows_in = sum(B * h * w for h, w in shapes)
+        out_shapes = [(-(-h // stride), -(-w // stride)) for h, w in shapes]
+        rows = sum(B * h * w for h, w in out_shapes)
         ld_w = (cout + 15) // 16 * 16
-        d = ops.make_conv_desc(B, shapes, shapes, cin, cout, k, stride, pad, pad, cin, ld_w, ld_w)
+        d = ops.make_conv_desc(B, shapes, out_shapes, cin, cout, k, stride, pad, pad, cin, ld_w, ld_w)
         g = torch.Generator(device="cuda").manual_seed(0)
-        x = torch.randn((rows, cin), device="cuda", generator=g)
+        x = torch.randn((rows_in, cin), device="cuda", generator=g)
         w = torch.randn((k * k * cin, ld_w), device="cuda", generator=g) * 0.02
         y = torch.empty((rows, ld_w), device="cuda")
         dy = torch.randn((rows, ld_w), device="cuda", generator=g)
         if ld_w != cout:
             dy[:, cout:] = 0
             w[:, cout:] = 0
-        dx = torch.empty((rows, cin), device="cuda")
+        dx = torch.empty((rows_in, cin), device="cuda")
         dw = torch.zeros((k * k * cin, ld_w), device="cuda")
         db = torch.zeros((ld_w,), device="cuda")
         bias = torch.zeros((ld_w,), device="cuda")
@@ -77,7 +84,7 @@ def main():
         ops.split_planes3(ctx, x, xh, xl)
         ops.split_planes3(ctx, dy, gh, gl)
         yh, yl = torch.zeros((rows, ld_w), **i16), torch.zeros((rows, ld_w), **i16)
-        dxh, dxl = torch.zeros((rows, cin), **i16), torch.zeros((rows, cin), **i16)
+        dxh, dxl = torch.zeros((rows_in, cin), **i16), torch.zeros((rows_in, cin), **i16)
         fns = {"fwd3pp": lambda: ops.conv_fwd3(ctx, d, None, fh, fl, bias, None, True, y, x_planes=(xh, xl), y_planes=(yh, yl)),
                "dgrad3pp": lambda: ops.conv_bwd_data3(ctx, d, None, dh, dl, None, x, dx, dy_planes=(gh, gl), dx_planes=(dxh, dxl)),
                "fwd3p": lambda: ops.conv_fwd3(ctx, d, None, fh, fl, bias, None, True, y, x_planes=(xh, xl)),
