@@ -249,6 +249,11 @@ size_t pp_filter_workspace_bytes(int n, int n_class, int max_det);
 int pp_filter_detections(pp_ctx* ctx, int n, int n_class, const float* boxes, const float* boxes3d,
                          const float* scores, float score_thr, float iou_thr, int max_det, void* workspace,
                          float* out_boxes, float* out_boxes3d, float* out_scores, int* out_labels);
+/* The same for n_img images in one set of launches (the Keras layer maps filter_detections over the batch,
+ * filter_detections.py:182-196): tensors gain a leading image dimension, workspace >= n_img * pp_filter_workspace_bytes. */
+int pp_filter_detections_batch(pp_ctx* ctx, int n_img, int n, int n_class, const float* boxes, const float* boxes3d,
+                               const float* scores, float score_thr, float iou_thr, int max_det, void* workspace,
+                               float* out_boxes, float* out_boxes3d, float* out_scores, int* out_labels);
 
 #ifdef __cplusplus
 }

@@ -114,6 +114,7 @@ _SIGS = {
     "pp_score_threshold_compact": (_i, [_p, _i, _i, _i, _p, _f, _i, _p, _p]),
     "pp_filter_workspace_bytes": (_sz, [_i, _i, _i]),
     "pp_filter_detections": (_i, [_p, _i, _i, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p]),
+    "pp_filter_detections_batch": (_i, [_p, _i, _i, _i, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p]),
 }
 
 EXPORTS = sorted(_SIGS)

@@ -36,9 +36,13 @@ __device__ __forceinline__ float key_score(unsigned long long k) {
 }
 
 // one workgroup per class: stable compaction of score > thr, then bitonic sort (score desc, index asc)
+// (blockIdx.y = image: every per-image tensor and workspace section is advanced by its image stride)
 __global__ void filter_sort_kernel(int n, int C, int npow2, const float* __restrict__ scores, float thr,
                                    unsigned long long* __restrict__ keys_all, int* __restrict__ cls_count) {
   const int c = blockIdx.x;
+  scores += (size_t)blockIdx.y * n * C;
+  keys_all += (size_t)blockIdx.y * C * npow2;
+  cls_count += (size_t)blockIdx.y * C;
   unsigned long long* keys = keys_all + (size_t)c * npow2;
   __shared__ int wave_cnt[16];
   __shared__ int base;
@@ -101,10 +105,15 @@ __device__ __forceinline__ float tf_iou(const float* a, const float* b) {
 }
 
 // one workgroup per class: greedy NMS over the sorted candidates, at most max_det survivors
-__global__ void filter_nms_kernel(int npow2, const float* __restrict__ boxes, float iou_thr, int max_det,
+__global__ void filter_nms_kernel(int n, int npow2, const float* __restrict__ boxes, float iou_thr, int max_det,
                                   const unsigned long long* __restrict__ keys_all, const int* __restrict__ cls_count,
                                   int* __restrict__ sel_idx_all, int* __restrict__ sel_count) {
-  const int c = blockIdx.x;
+  const int c = blockIdx.x, C = gridDim.x;
+  boxes += (size_t)blockIdx.y * n * 4;
+  keys_all += (size_t)blockIdx.y * C * npow2;
+  cls_count += (size_t)blockIdx.y * C;
+  sel_idx_all += (size_t)blockIdx.y * C * max_det;
+  sel_count += (size_t)blockIdx.y * C;
   const unsigned long long* keys = keys_all + (size_t)c * npow2;
   int* sel_idx = sel_idx_all + (size_t)c * max_det;
   extern __shared__ float s_boxes[];  // [max_det][4]
@@ -127,10 +136,16 @@ __global__ void filter_nms_kernel(int npow2, const float* __restrict__ boxes, fl
 }
 
 // single workgroup: concat classes, top_k by score (ties: earlier position first), gather, pad with -1
-__global__ void filter_topk_kernel(int C, int max_det, const float* __restrict__ boxes, const float* __restrict__ boxes3d,
+__global__ void filter_topk_kernel(int n, int C, int max_det, const float* __restrict__ boxes, const float* __restrict__ boxes3d,
                                    const float* __restrict__ scores, const int* __restrict__ sel_idx_all,
                                    const int* __restrict__ sel_count, float* __restrict__ out_boxes,
                                    float* __restrict__ out_boxes3d, float* __restrict__ out_scores, int* __restrict__ out_labels) {
+  {
+    const size_t b = blockIdx.x;
+    boxes += b * n * 4; boxes3d += b * n * 16; scores += b * n * C;
+    sel_idx_all += b * C * max_det; sel_count += b * C;
+    out_boxes += b * max_det * 4; out_boxes3d += b * max_det * 16; out_scores += b * max_det; out_labels += b * max_det;
+  }
   extern __shared__ unsigned long long s_keys[];  // [len] (score, position); then position -> (class, slot)
   __shared__ int s_off[64 + 1];
   if (threadIdx.x == 0) {
@@ -186,32 +201,39 @@ __global__ void filter_topk_kernel(int C, int max_det, const float* __restrict__
   }
 }
 
-extern "C" int pp_filter_detections(pp_ctx* ctx, int n, int n_class, const float* boxes, const float* boxes3d, const float* scores,
-                                    float score_thr, float iou_thr, int max_det, void* workspace, float* out_boxes,
-                                    float* out_boxes3d, float* out_scores, int* out_labels) {
+extern "C" int pp_filter_detections_batch(pp_ctx* ctx, int n_img, int n, int n_class, const float* boxes, const float* boxes3d,
+                                          const float* scores, float score_thr, float iou_thr, int max_det, void* workspace,
+                                          float* out_boxes, float* out_boxes3d, float* out_scores, int* out_labels) {
   PP_REQUIRE_CTX(ctx);
-  PP_CHECK_ARG(ctx, n > 0 && n_class > 0 && n_class <= 64 && max_det > 0 && max_det <= 1024, PP_ERR_SHAPE,
-               "pp_filter_detections: unsupported size (classes <= 64, max_det <= 1024)");
+  PP_CHECK_ARG(ctx, n_img > 0 && n_img <= 65535 && n > 0 && n_class > 0 && n_class <= 64 && max_det > 0 && max_det <= 1024, PP_ERR_SHAPE,
+               "pp_filter_detections: unsupported size (images <= 65535, classes <= 64, max_det <= 1024)");
   PP_CHECK_ARG(ctx, boxes && boxes3d && scores && workspace && out_boxes && out_boxes3d && out_scores && out_labels, PP_ERR_ARG,
                "pp_filter_detections: null argument");
   const int np2 = next_pow2(n);
-  char* w = (char*)workspace;
+  char* w = (char*)workspace;  // sections are [image][...], each image's block as pp_filter_workspace_bytes lays it out
   FilterWs ws;
   ws.keys = (unsigned long long*)w;
-  w += (size_t)n_class * np2 * 8;
+  w += (size_t)n_img * n_class * np2 * 8;
   ws.cls_count = (int*)w;
-  w += (size_t)n_class * 4;
+  w += (size_t)n_img * n_class * 4;
   ws.sel_count = (int*)w;
-  w += (size_t)n_class * 4;
+  w += (size_t)n_img * n_class * 4;
   ws.sel_idx = (int*)w;
-  hipLaunchKernelGGL(filter_sort_kernel, dim3(n_class), dim3(1024), 0, ctx->stream, n, n_class, np2, scores, score_thr, ws.keys,
-                     ws.cls_count);
-  hipLaunchKernelGGL(filter_nms_kernel, dim3(n_class), dim3(256), (size_t)max_det * 16, ctx->stream, np2, boxes, iou_thr, max_det,
-                     (const unsigned long long*)ws.keys, (const int*)ws.cls_count, ws.sel_idx, ws.sel_count);
   const int tot_max = next_pow2(n_class * max_det);
   PP_CHECK_ARG(ctx, (size_t)tot_max * 8 <= 64 * 1024, PP_ERR_SHAPE, "pp_filter_detections: classes*max_det too large for the top-k stage");
-  hipLaunchKernelGGL(filter_topk_kernel, dim3(1), dim3(1024), (size_t)tot_max * 8, ctx->stream, n_class, max_det, boxes, boxes3d,
+  hipLaunchKernelGGL(filter_sort_kernel, dim3(n_class, n_img), dim3(1024), 0, ctx->stream, n, n_class, np2, scores, score_thr, ws.keys,
+                     ws.cls_count);
+  hipLaunchKernelGGL(filter_nms_kernel, dim3(n_class, n_img), dim3(256), (size_t)max_det * 16, ctx->stream, n, np2, boxes, iou_thr, max_det,
+                     (const unsigned long long*)ws.keys, (const int*)ws.cls_count, ws.sel_idx, ws.sel_count);
+  hipLaunchKernelGGL(filter_topk_kernel, dim3(n_img), dim3(1024), (size_t)tot_max * 8, ctx->stream, n, n_class, max_det, boxes, boxes3d,
                      scores, (const int*)ws.sel_idx, (const int*)ws.sel_count, out_boxes, out_boxes3d, out_scores, out_labels);
   PP_CHECK_LAUNCH(ctx, "pp_filter_detections");
   return PP_OK;
+}
+
+extern "C" int pp_filter_detections(pp_ctx* ctx, int n, int n_class, const float* boxes, const float* boxes3d, const float* scores,
+                                    float score_thr, float iou_thr, int max_det, void* workspace, float* out_boxes,
+                                    float* out_boxes3d, float* out_scores, int* out_labels) {
+  return pp_filter_detections_batch(ctx, 1, n, n_class, boxes, boxes3d, scores, score_thr, iou_thr, max_det, workspace, out_boxes,
+                                    out_boxes3d, out_scores, out_labels);
 }

@@ -55,6 +55,5 @@ class FilterDetections(object):
     def __call__(self, inputs):
         boxes, boxes3D, classification = inputs[0], inputs[1], inputs[2]
         ctx = default_context()
-        outs = [ops.filter_detections(ctx, boxes[b].contiguous(), boxes3D[b].contiguous(), classification[b].contiguous(),
-                                      self.score_threshold, self.nms_threshold, self.max_detections) for b in range(boxes.shape[0])]
-        return [torch.stack([o[i] for o in outs]) for i in range(4)]
+        return list(ops.filter_detections_batch(ctx, boxes.contiguous(), boxes3D.contiguous(), classification.contiguous(),
+                                                self.score_threshold, self.nms_threshold, self.max_detections))

@@ -309,6 +309,19 @@ def score_threshold_compact(ctx, scores, thr=0.5, cap=None):
     return idx, cnt
 
 
+def filter_detections_batch(ctx, boxes, boxes3d, scores, score_thr=0.05, iou_thr=0.5, max_det=300):
+    """boxes [B,N,4], boxes3d [B,N,16], scores [B,N,C] -> ([B,max_det,4], [B,max_det,16], [B,max_det], [B,max_det] int32)."""
+    Bn, N, Cc = scores.shape
+    ws = torch.empty((Bn * lib.pp_filter_workspace_bytes(N, Cc, max_det),), dtype=torch.uint8, device="cuda")
+    ob = torch.empty((Bn, max_det, 4), dtype=torch.float32, device="cuda")
+    o3 = torch.empty((Bn, max_det, 16), dtype=torch.float32, device="cuda")
+    osc = torch.empty((Bn, max_det), dtype=torch.float32, device="cuda")
+    ol = torch.empty((Bn, max_det), dtype=torch.int32, device="cuda")
+    check(lib.pp_filter_detections_batch(ctx.handle, Bn, N, Cc, _ptr(boxes), _ptr(boxes3d), _ptr(scores), score_thr, iou_thr, max_det,
+                                         _ptr(ws), _ptr(ob), _ptr(o3), _ptr(osc), _ptr(ol)), ctx.handle, "pp_filter_detections_batch")
+    return ob, o3, osc, ol
+
+
 def filter_detections(ctx, boxes, boxes3d, scores, score_thr=0.05, iou_thr=0.5, max_det=300):
     N, Cc = scores.shape
     ws = torch.empty((lib.pp_filter_workspace_bytes(N, Cc, max_det),), dtype=torch.uint8, device="cuda")

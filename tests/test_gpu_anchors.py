@@ -173,3 +173,20 @@ def test_filter_detections_vs_oracle(ctx):
     want = D.filter_detections(boxes, boxes3d, scores, 0.05, 300, 0.5)
     for g, w in zip(got, want):
         assert np.array_equal(g.cpu().numpy(), w)
+
+
+def test_filter_detections_batch_matches_per_image(ctx):
+    """pp_filter_detections_batch (grid.y = image) == the single-image entry, image by image (different candidate counts)."""
+    from pyrapose_amd import ops
+    rng = np.random.default_rng(21)
+    B, N, C = 3, 2500, 4
+    ctr = rng.uniform(50, 400, size=(B, N, 2)); wh = rng.uniform(20, 120, size=(B, N, 2))
+    boxes = torch.from_numpy(np.concatenate([ctr - wh / 2, ctr + wh / 2], axis=-1).astype(np.float32)).cuda()
+    boxes3d = torch.from_numpy(rng.uniform(0, 640, size=(B, N, 16)).astype(np.float32)).cuda()
+    sc = rng.uniform(0, 1, size=(B, N, C)) ** np.array([2.0, 6.0, 12.0]).reshape(B, 1, 1)
+    scores = torch.from_numpy(sc.astype(np.float32)).cuda()
+    got = ops.filter_detections_batch(ctx, boxes, boxes3d, scores, 0.05, 0.5, 300)
+    for b in range(B):
+        want = ops.filter_detections(ctx, boxes[b].contiguous(), boxes3d[b].contiguous(), scores[b].contiguous(), 0.05, 0.5, 300)
+        for g, w in zip(got, want):
+            assert torch.equal(g[b], w)

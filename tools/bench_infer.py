@@ -40,11 +40,9 @@ def main():
         boxes3d, scores, mask = eng.predict_on_batch(x)
         idx = ops.score_threshold_compact(ctx, scores, 0.5)
         if args.nms:
-            for b in range(B):
-                b3 = boxes3d[b]
-                xs, ys = b3[:, 0::2], b3[:, 1::2]
-                boxes = torch.stack([xs.min(1).values, ys.min(1).values, xs.max(1).values, ys.max(1).values], 1).contiguous()
-                ops.filter_detections(ctx, boxes, b3, scores[b], 0.05, 0.5, 300)
+            xs, ys = boxes3d[..., 0::2], boxes3d[..., 1::2]
+            boxes = torch.stack([xs.amin(-1), ys.amin(-1), xs.amax(-1), ys.amax(-1)], -1).contiguous()
+            ops.filter_detections_batch(ctx, boxes, boxes3d, scores, 0.05, 0.5, 300)
         return scores, idx
 
     for _ in range(args.warmup):
