@@ -147,6 +147,9 @@ int pp_upsample_nearest_add_bwd(pp_ctx* ctx, int n_img, int sh, int sw, int th, 
                                 const float* dtarget, const float* base, float* dsrc);
 /* out = a + b (+ c)   (keras.layers.Add, models/retinanet.py:198-211); b, c may be NULL */
 int pp_add_n(pp_ctx* ctx, size_t n, const float* a, const float* b, const float* c, float* out);
+/* y = max(x, 0): the stand-alone Activation('relu') between P6 and the P7 conv of __create_pyramid_features
+ * (models/retinanet.py:154).  Its backward is the relu_src mask of the consumer's pp_conv2d_nhwc_bwd_data*. */
+int pp_relu_fwd(pp_ctx* ctx, size_t n, const float* x, float* y);
 /* [n_img,h,w,3] -> [n_img,h,w,4] zero-padded channel (feeds conv1 as cin == 4) */
 int pp_pack_rgb_to_4(pp_ctx* ctx, size_t n_pixels, const float* x3, float* x4);
 

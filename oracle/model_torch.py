@@ -124,6 +124,24 @@ def sparse_fpn(C3, C4, C5, W, dtype):
     return P3, P4, P5
 
 
+def pyramid_features(C3, C4, C5, W, dtype, with_p6p7=True):
+    """models/retinanet.py:134-157 (__create_pyramid_features, P3..P7) / :160-177 (__create_FPN, P3..P5)."""
+    def cv(name, x, k, s=1):
+        return conv2d(x, _t(W[name + "/kernel"], dtype), _t(W[name + "/bias"], dtype), s, "same")
+    P5 = cv("C5_reduced", C5, 1)                                        # :135
+    U5 = upsample_like(P5, C4)                                          # :136
+    P5 = cv("P5_con", P5, 3)                                            # :137
+    P4 = cv("C4_reduced", C4, 1) + U5                                   # :140-141
+    U4 = upsample_like(P4, C3)                                          # :142
+    P4 = cv("P4_con", P4, 3)                                            # :143
+    P3 = cv("P3_con", cv("C3_reduced", C3, 1) + U4, 3)                  # :146-148
+    if not with_p6p7:
+        return [P3, P4, P5]
+    P6 = cv("P6_con", C5, 3, 2)                                         # :151 "3x3 stride-2 conv on C5"
+    P7 = cv("P7_con", F.relu(P6), 3, 2)                                 # :154-155
+    return [P3, P4, P5, P6, P7]
+
+
 def head(prefix, feat, W, dtype, n_values):
     """4 x [3x3 conv + ReLU] + 3x3 conv, then Reshape((-1, n_values)) on NHWC."""
     y = feat
@@ -133,13 +151,16 @@ def head(prefix, feat, W, dtype, n_values):
     return y.permute(0, 2, 3, 1).reshape(y.shape[0], -1, n_values)
 
 
-def forward(W, x_nhwc, num_classes, dtype=torch.float32, blocks=None, return_features=False):
+def forward(W, x_nhwc, num_classes, dtype=torch.float32, blocks=None, return_features=False, pyramid="sparse"):
     """x_nhwc: (B,H,W,3) preprocessed image batch.  Returns dict with '3Dbox', 'cls', 'mask' (Keras
     outputs: cls/mask are probabilities) plus the pre-sigmoid logits."""
     x = _t(x_nhwc, dtype).permute(0, 3, 1, 2)
     C2, C3, C4, C5 = resnet50(x, W, dtype, blocks)
-    P3, P4, P5 = sparse_fpn(C3, C4, C5, W, dtype)
-    feats = [P3, P4, P5]
+    if pyramid == "sparse":
+        feats = list(sparse_fpn(C3, C4, C5, W, dtype))
+    else:
+        feats = pyramid_features(C3, C4, C5, W, dtype, with_p6p7=(pyramid == "p3p7"))
+    P3, P4, P5 = feats[:3]
     reg = torch.cat([head("reg", f, W, dtype, 16) for f in feats], dim=1)
     cls_logit = torch.cat([head("cls", f, W, dtype, num_classes) for f in feats], dim=1)
     mask_logit = head("mask", P3, W, dtype, num_classes)
@@ -224,14 +245,14 @@ def trainable_names(W):
     return sorted(names)
 
 
-def loss_and_grads(W, x_nhwc, y_box, y_cls, y_mask, num_classes, dtype=torch.float64, blocks=None):
+def loss_and_grads(W, x_nhwc, y_box, y_cls, y_mask, num_classes, dtype=torch.float64, blocks=None, pyramid="sparse"):
     """Total Keras training loss = orthogonal_l1('3Dbox') + focal('cls') + focal('mask') + L2 reg
     (bin/train.py:95-102), and its gradient w.r.t. every trainable tensor."""
     names = trainable_names(W)
     Wt = {k: _t(v, dtype) for k, v in W.items()}
     for k in names:
         Wt[k].requires_grad_(True)
-    out = forward(Wt, x_nhwc, num_classes, dtype, blocks)
+    out = forward(Wt, x_nhwc, num_classes, dtype, blocks, pyramid=pyramid)
     l_box = orthogonal_l1(_t(y_box, dtype), out["3Dbox"])
     l_cls = focal(_t(y_cls, dtype), out["cls"])
     l_mask = focal(_t(y_mask, dtype), out["mask"])

@@ -54,7 +54,20 @@ def backbone_specs(backbone="resnet50"):
     return specs
 
 
-def fpn_specs():
+PYRAMIDS = ("sparse", "fpn", "p3p7")
+PYRAMID_LEVELS = {"sparse": (3, 4, 5), "fpn": (3, 4, 5), "p3p7": (3, 4, 5, 6, 7)}
+
+
+def fpn_specs(pyramid="sparse"):
+    """'sparse' = __create_sparceFPN (models/retinanet.py:180-214, what retinanet() builds on master);
+    'fpn' = __create_FPN (:160-177); 'p3p7' = __create_pyramid_features (:134-157).  The lateral 1x1 convs are unnamed
+    in the reference (Keras auto-names); here C{3,4,5}_reduced.  P{3..7}_con are the reference's names."""
+    if pyramid != "sparse":
+        s = [ConvSpec("C5_reduced", 2048, 256, 1), ConvSpec("P5_con", 256, 256, 3), ConvSpec("C4_reduced", 1024, 256, 1),
+             ConvSpec("P4_con", 256, 256, 3), ConvSpec("C3_reduced", 512, 256, 1), ConvSpec("P3_con", 256, 256, 3)]
+        if pyramid == "p3p7":
+            s += [ConvSpec("P6_con", 2048, 256, 3, 2), ConvSpec("P7_con", 256, 256, 3, 2)]
+        return s
     s = [ConvSpec("fpn_lat3", 512, 256, 1), ConvSpec("fpn_lat4", 1024, 256, 1), ConvSpec("fpn_lat5", 2048, 256, 1),
          ConvSpec("fpn_mid4", 256, 256, 3), ConvSpec("fpn_mid3", 256, 256, 3), ConvSpec("fpn_down3", 256, 256, 3, 2),
          ConvSpec("P3", 256, 256, 3), ConvSpec("fpn_down4", 256, 256, 3, 2), ConvSpec("P4", 256, 256, 3),
@@ -77,17 +90,18 @@ def head_specs(num_classes, num_anchors=NUM_ANCHORS):
     return s
 
 
-def all_specs(num_classes, backbone="resnet50"):
-    return backbone_specs(backbone) + fpn_specs() + head_specs(num_classes)
+def all_specs(num_classes, backbone="resnet50", pyramid="sparse", num_anchors=NUM_ANCHORS):
+    assert pyramid in PYRAMIDS, pyramid
+    return backbone_specs(backbone) + fpn_specs(pyramid) + head_specs(num_classes, num_anchors)
 
 
-def init_weights(num_classes, seed=0, backbone="resnet50"):
+def init_weights(num_classes, seed=0, backbone="resnet50", pyramid="sparse", num_anchors=NUM_ANCHORS):
     """Random-init weights of the reference architecture (no network for the ImageNet file):
     heads N(0, 0.01) / zeros / PriorProbability (retinanet.py:35-43,80-88,106-107), FPN Keras default
     glorot_uniform + zero bias, backbone He-normal stand-in with a random frozen-BN affine."""
     rng = np.random.default_rng(seed)
     W = OrderedDict()
-    for s in all_specs(num_classes, backbone):
+    for s in all_specs(num_classes, backbone, pyramid, num_anchors):
         fan_in, fan_out = s.k * s.k * s.cin, s.k * s.k * s.cout
         shape = (s.k, s.k, s.cin, s.cout)
         if s.init == "normal001":

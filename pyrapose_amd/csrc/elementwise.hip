@@ -140,6 +140,25 @@ __global__ void add_n_kernel(size_t n4, const float4* __restrict__ a, const floa
   }
 }
 
+// keras.layers.Activation('relu') as its own op (models/retinanet.py:154: ReLU between P6 and the P7 conv); its gradient
+// mask is applied by the consumer conv's bwd-data epilogue (relu_src), like every other ReLU of the graph
+__global__ void relu_kernel(size_t n4, const float4* __restrict__ x, float4* __restrict__ y) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 v = x[i];
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    y[i] = v;
+  }
+}
+
+extern "C" int pp_relu_fwd(pp_ctx* ctx, size_t n, const float* x, float* y) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, x && y && n % 4 == 0, PP_ERR_SHAPE, "pp_relu_fwd: n must be a multiple of 4");
+  if (n == 0) return PP_OK;
+  hipLaunchKernelGGL(relu_kernel, dim3(grid_for(n / 4, 256, ctx)), dim3(256), 0, ctx->stream, n / 4, (const float4*)x, (float4*)y);
+  PP_CHECK_LAUNCH(ctx, "pp_relu_fwd");
+  return PP_OK;
+}
+
 extern "C" int pp_add_n(pp_ctx* ctx, size_t n, const float* a, const float* b, const float* c, float* out) {
   PP_REQUIRE_CTX(ctx);
   PP_CHECK_ARG(ctx, a && out && n % 4 == 0, PP_ERR_SHAPE, "pp_add_n: n must be a multiple of 4");

@@ -171,20 +171,30 @@ class ParamStore(object):
 
 class Engine(object):
     def __init__(self, ctx, num_classes, batch, height, width, backbone="resnet50", weights=None, train=True, seed=0,
-                 lr=1e-5, clipnorm=0.001, freeze_backbone=False, conv_mode=None):
+                 lr=1e-5, clipnorm=0.001, freeze_backbone=False, conv_mode=None, pyramid="sparse", anchor_params=None):
+        """pyramid: 'sparse' (__create_sparceFPN, what the reference's retinanet() builds), 'fpn' (__create_FPN) or 'p3p7'
+        (__create_pyramid_features: P3..P7).  anchor_params: utils.anchors.AnchorParameters (sizes / strides per level);
+        default: the reference default for 3 levels, the 5-level RetinaNet sizes 32..512 for 'p3p7'."""
         self.ctx, self.C, self.B, self.H, self.W = ctx, int(num_classes), int(batch), int(height), int(width)
-        self.A = arch.NUM_ANCHORS
+        assert pyramid in arch.PYRAMIDS, pyramid
+        self.pyramid = pyramid
+        from .utils import anchors as _ua
+        if anchor_params is None:
+            anchor_params = _ua.AnchorParameters.default if pyramid != "p3p7" else _ua.AnchorParameters.p3p7
+        self.anchor_params = anchor_params
+        self.A = anchor_params.num_anchors()
+        assert len(anchor_params.sizes) == len(arch.PYRAMID_LEVELS[pyramid]), "anchor_params need one size / stride per pyramid level"
         self.backbone = backbone
         self.train = train
         self.lr, self.clipnorm = lr, clipnorm
         self.beta1, self.beta2, self.eps = 0.9, 0.999, 1e-7
-        self.specs = arch.all_specs(self.C, backbone)
+        self.specs = arch.all_specs(self.C, backbone, pyramid, self.A)
         if freeze_backbone:  # --freeze-backbone: utils/model.py:18-27 freeze() applied to the ResNet (bin/train.py:74)
             for s in self.specs:
                 if s.bn:
                     s.trainable = False
         self.params = ParamStore(self.specs, train)
-        self.params.load(weights if weights is not None else arch.init_weights(self.C, seed, backbone))
+        self.params.load(weights if weights is not None else arch.init_weights(self.C, seed, backbone, pyramid, self.A))
         # conv arithmetic: "bf16x3" (default) = 3 x bf16 MFMA per product, f32 accumulation (conv3.hip; ~2^-16 per
         # product, whole-graph outputs within 2e-5 of the f32 path) for every conv except the 3-channel stem;
         # "f32" = exact f32 MFMA everywhere (conv.hip).  Both hold the 1e-3 head-output bar.
@@ -217,7 +227,7 @@ class Engine(object):
         self.acts = OrderedDict()
         self.step_count = 0
         self._build_forward()
-        self.levels = arch.level_shapes(self.H, self.W)
+        self.levels = arch.level_shapes(self.H, self.W, arch.PYRAMID_LEVELS[pyramid])
         assert [tuple(s) for s in self.pyr.shapes] == [tuple(s) for s in self.levels], (self.pyr.shapes, self.levels)
         self.N = sum(h * w for h, w in self.levels) * self.A
         self.M3 = self.levels[0][0] * self.levels[0][1]
@@ -329,35 +339,10 @@ class Engine(object):
             stage_out.append(y)
         C3, C4, C5 = stage_out[1], stage_out[2], stage_out[3]
         self.C3, self.C4, self.C5 = C3, C4, C5
-        # ---- __create_sparceFPN (models/retinanet.py:180-214)
-        L3 = self._conv("fpn_lat3", C3)
-        L4 = self._conv("fpn_lat4", C4)
-        L5 = self._conv("fpn_lat5", C5)
-        S4 = self._upadd("fpn_sum4", L5, L4)
-        S3 = self._upadd("fpn_sum3", L4, L3)
-        M4 = self._conv("fpn_mid4", S4)
-        M3 = self._conv("fpn_mid3", S3)
-        D3 = self._conv("fpn_down3", M3)
-        F3 = self._add("fpn_fin3", [M3, L3])
-        # pyramid buffer: P3 | P4 | P5 rows, so that the shared heads run as ONE multi-level launch
-        lv = [L3.shapes[0], L4.shapes[0], L5.shapes[0]]
-        rows = [B * h * w for h, w in lv]
-        pyr_t = torch.empty((sum(rows), 256), dtype=torch.float32, device="cuda")
-        cuts = [(0, rows[0]), (rows[0], rows[0] + rows[1]), (rows[0] + rows[1], sum(rows))]
-        sl = [pyr_t[a:b] for a, b in cuts]
-        pyr_pl = _new_planes(sum(rows), 256) if self.use_act_planes else None
-        spl = [(pyr_pl[0][a:b], pyr_pl[1][a:b]) if pyr_pl else None for a, b in cuts]
-        P3 = self._conv("P3", F3, out_t=sl[0], out_pl=spl[0])
-        F4 = self._add("fpn_fin4", [D3, M4, L4])
-        D4 = self._conv("fpn_down4", M4)
-        P4 = self._conv("P4", F4, out_t=sl[1], out_pl=spl[1])
-        F5 = self._add("fpn_fin5", [D4, L5])
-        P5 = self._conv("P5", F5, out_t=sl[2], out_pl=spl[2])
-        needs = self.train
-        pyr = self._new_act("pyramid", lv, 256, 256, needs, False, pyr_t)
-        pyr.pl = pyr_pl
-        pyr.producer = getattr(P3, "producer", None)
-        self.graph_ops.append(dict(kind="alias", y=pyr, parts=[P3, P4, P5], rows=rows))
+        if self.pyramid == "sparse":
+            pyr, P3 = self._build_sparse_fpn(C3, C4, C5)
+        else:
+            pyr, P3 = self._build_pyramid_features(C3, C4, C5)
         self.pyr, self.P3 = pyr, P3
         # ---- heads (models/retinanet.py:9-131, shared across levels :224-225; mask on P3 only :296)
         def run_head(prefix, feat):
@@ -386,6 +371,80 @@ class Engine(object):
         for a in self.acts.values():
             if a.pl is not None and not getattr(a, "conv3_consumers", 0) and a.pl[0]._base is None:  # (P4/P5 write slices of pyr's)
                 a.pl = None
+
+    def _pyramid_buffer(self, level_shapes):
+        """P3 | P4 | ... rows in one buffer, so that the shared heads run as ONE multi-level launch"""
+        B = self.B
+        rows = [B * h * w for h, w in level_shapes]
+        pyr_t = torch.empty((sum(rows), 256), dtype=torch.float32, device="cuda")
+        cuts, r0 = [], 0
+        for n in rows:
+            cuts.append((r0, r0 + n))
+            r0 += n
+        sl = [pyr_t[a:b] for a, b in cuts]
+        pyr_pl = _new_planes(sum(rows), 256) if self.use_act_planes else None
+        spl = [(pyr_pl[0][a:b], pyr_pl[1][a:b]) if pyr_pl else None for a, b in cuts]
+        return pyr_t, pyr_pl, rows, sl, spl
+
+    def _build_sparse_fpn(self, C3, C4, C5):
+        """__create_sparceFPN (models/retinanet.py:180-214)"""
+        L3 = self._conv("fpn_lat3", C3)
+        L4 = self._conv("fpn_lat4", C4)
+        L5 = self._conv("fpn_lat5", C5)
+        S4 = self._upadd("fpn_sum4", L5, L4)
+        S3 = self._upadd("fpn_sum3", L4, L3)
+        M4 = self._conv("fpn_mid4", S4)
+        M3 = self._conv("fpn_mid3", S3)
+        D3 = self._conv("fpn_down3", M3)
+        F3 = self._add("fpn_fin3", [M3, L3])
+        lv = [L3.shapes[0], L4.shapes[0], L5.shapes[0]]
+        pyr_t, pyr_pl, rows, sl, spl = self._pyramid_buffer(lv)
+        P3 = self._conv("P3", F3, out_t=sl[0], out_pl=spl[0])
+        F4 = self._add("fpn_fin4", [D3, M4, L4])
+        D4 = self._conv("fpn_down4", M4)
+        P4 = self._conv("P4", F4, out_t=sl[1], out_pl=spl[1])
+        F5 = self._add("fpn_fin5", [D4, L5])
+        P5 = self._conv("P5", F5, out_t=sl[2], out_pl=spl[2])
+        needs = self.train
+        pyr = self._new_act("pyramid", lv, 256, 256, needs, False, pyr_t)
+        pyr.pl = pyr_pl
+        pyr.producer = getattr(P3, "producer", None)
+        self.graph_ops.append(dict(kind="alias", y=pyr, parts=[P3, P4, P5], rows=rows))
+        return pyr, P3
+
+    def _build_pyramid_features(self, C3, C4, C5):
+        """__create_pyramid_features (models/retinanet.py:134-157; P3..P7) / __create_FPN (:160-177; P3..P5)"""
+        R5 = self._conv("C5_reduced", C5)
+        R4 = self._conv("C4_reduced", C4)
+        R3 = self._conv("C3_reduced", C3)
+        S4 = self._upadd("td_sum4", R5, R4)   # P5_upsampled + P4   (:136,141)
+        S3 = self._upadd("td_sum3", S4, R3)   # P4_upsampled + P3   (:142,147)
+        lv = [R3.shapes[0], R4.shapes[0], R5.shapes[0]]
+        if self.pyramid == "p3p7":
+            s6 = (-(-R5.shapes[0][0] // 2), -(-R5.shapes[0][1] // 2))
+            lv += [s6, (-(-s6[0] // 2), -(-s6[1] // 2))]
+        pyr_t, pyr_pl, rows, sl, spl = self._pyramid_buffer(lv)
+        P3 = self._conv("P3_con", S3, out_t=sl[0], out_pl=spl[0])
+        P4 = self._conv("P4_con", S4, out_t=sl[1], out_pl=spl[1])
+        P5 = self._conv("P5_con", R5, out_t=sl[2], out_pl=spl[2])
+        parts = [P3, P4, P5]
+        if self.pyramid == "p3p7":
+            P6 = self._conv("P6_con", C5, out_t=sl[3], out_pl=spl[3])           # "3x3 stride-2 conv on C5" (:151)
+            R6 = self._relu("P6_relu", P6)                                      # :154
+            P7 = self._conv("P7_con", R6, out_t=sl[4], out_pl=spl[4])           # :155
+            parts += [P6, P7]
+        pyr = self._new_act("pyramid", lv, 256, 256, self.train, False, pyr_t)
+        pyr.pl = pyr_pl
+        pyr.producer = getattr(P3, "producer", None)
+        self.graph_ops.append(dict(kind="alias", y=pyr, parts=parts, rows=rows))
+        return pyr, P3
+
+    def _relu(self, name, x):
+        out = self._new_act(name, x.shapes, x.C, x.ld, x.needs_grad, True)
+        ctx = self.ctx
+        self.fwd_ops.append(Op(lambda: ops.relu_fwd(ctx, x.t, out.t), "pointwise", name))
+        self.graph_ops.append(dict(kind="relu", y=out, x=x))
+        return out
 
     def _upadd(self, name, src, other):
         (sh, sw), (th, tw) = src.shapes[0], other.shapes[0]
@@ -534,6 +593,10 @@ class Engine(object):
                     self.bwd_ops.append(Op(lambda g=g, gs=gs, sh=sh, sw=sw, th=th, tw=tw, c=src.C:
                                            ops.upsample_add_bwd(ctx, self.B, sh, sw, th, tw, c, g.t, None, gs), "pointwise", "upbwd:" + src.name))
                     src.contribs.append(("tensor", Grad(gs)))
+            elif kind == "relu":
+                # `g` already carries the mask (y > 0): _finalize folded it into the data-gradient launch that produced it
+                if op["x"].needs_grad:
+                    op["x"].contribs.append(("tensor", g))
             elif kind == "alias":
                 r0 = 0
                 for part, n in zip(op["parts"], op["rows"]):
@@ -578,7 +641,7 @@ class Engine(object):
     def anchors_device_f32(self):
         if self.anchors_f32 is None:
             from .utils import anchors as ua
-            p = ua.AnchorParameters.default
+            p = self.anchor_params
             base = np.stack([ops.generate_base_anchors(sz, p.ratios, p.scales) for sz in p.sizes[: len(self.levels)]])
             self.anchors_f32 = ops.anchors_shift(self.ctx, self.levels, p.strides[: len(self.levels)], base, torch.float32)
         return self.anchors_f32

@@ -36,18 +36,25 @@ class _LayerHandle(object):
 class PyraPoseModel(object):
     """Training model: outputs ['3Dbox' (B,N,16), 'cls' (B,N,C), 'mask' (B,HW/64,C)]."""
 
-    def __init__(self, num_classes, backbone="resnet50", weights=None, seed=0, freeze_backbone=False, name="retinanet"):
+    def __init__(self, num_classes, backbone="resnet50", weights=None, seed=0, freeze_backbone=False, name="retinanet",
+                 pyramid="sparse", anchor_params=None):
+        """pyramid: which `create_pyramid_features` of models/retinanet.py:260-299 to build -- 'sparse' (the default
+        there, __create_sparceFPN), 'fpn' (__create_FPN) or 'p3p7' (__create_pyramid_features)."""
+        from ..utils.anchors import AnchorParameters
         self.name = name
         self.num_classes = int(num_classes)
         self.backbone_name = backbone
+        self.pyramid = pyramid
+        self.anchor_params = anchor_params or (AnchorParameters.p3p7 if pyramid == "p3p7" else AnchorParameters.default)
         self.output_names = list(OUTPUT_NAMES)
-        self._weights = weights if weights is not None else arch.init_weights(self.num_classes, seed, backbone)
+        na = self.anchor_params.num_anchors()
+        self._weights = weights if weights is not None else arch.init_weights(self.num_classes, seed, backbone, pyramid, na)
         self._engine = None
         self._loss = None
         self._optimizer = None
         self.freeze_backbone = freeze_backbone
         self.stop_training = False
-        self.layers = [_LayerHandle(s.name, self) for s in arch.all_specs(self.num_classes, backbone)]
+        self.layers = [_LayerHandle(s.name, self) for s in arch.all_specs(self.num_classes, backbone, pyramid, na)]
 
     # ---- engine management ---------------------------------------------------------------------
     def _get_engine(self, B, H, W, train):
@@ -59,7 +66,8 @@ class PyraPoseModel(object):
         lr = self._optimizer.lr if self._optimizer else 1e-5
         clip = self._optimizer.clipnorm if self._optimizer else 0.001
         self._engine = Engine(default_context(), self.num_classes, B, H, W, self.backbone_name, self._weights,
-                              train=train, lr=lr, clipnorm=clip, freeze_backbone=self.freeze_backbone)
+                              train=train, lr=lr, clipnorm=clip, freeze_backbone=self.freeze_backbone, pyramid=self.pyramid,
+                              anchor_params=self.anchor_params)
         if self._optimizer is not None:
             self._engine.beta1, self._engine.beta2, self._engine.eps = self._optimizer.beta_1, self._optimizer.beta_2, self._optimizer.epsilon
         if train and int(os.environ.get("WORLD_SIZE", "1")) > 1:

@@ -40,7 +40,11 @@ class ResNetBackbone(Backbone):
 def resnet_retinanet(num_classes, inputs=None, modifier=None, backbone="resnet50", num_anchors=None, **kwargs):
     """models/resnet.py:79-110.  The reference hard-codes ResNet50 whatever the name says; we honour
     the requested depth.  ``modifier`` (freeze_model, bin/train.py:74) marks the backbone frozen."""
-    m = PyraPoseModel(num_classes, backbone.split("_")[0], freeze_backbone=modifier is not None)
+    # create_pyramid_features (models/retinanet.py:265) is selected by name here: pyramid='sparse' | 'fpn' | 'p3p7'
+    m = PyraPoseModel(num_classes, backbone.split("_")[0], freeze_backbone=modifier is not None,
+                      pyramid=kwargs.get("pyramid", "sparse"), anchor_params=kwargs.get("anchor_params"))
+    if num_anchors is not None and num_anchors != m.anchor_params.num_anchors():
+        raise ValueError("num_anchors=%d does not match anchor_params (%d)" % (num_anchors, m.anchor_params.num_anchors()))
     return m
 
 

@@ -161,6 +161,10 @@ def add_n(ctx, a, b, c, out):
     check(lib.pp_add_n(ctx.handle, a.numel(), _ptr(a), _ptr(b), _ptr(c), _ptr(out)), ctx.handle, "pp_add_n")
 
 
+def relu_fwd(ctx, x, y):
+    check(lib.pp_relu_fwd(ctx.handle, x.numel(), _ptr(x), _ptr(y)), ctx.handle, "pp_relu_fwd")
+
+
 def pack_rgb_to_4(ctx, x3, x4):
     check(lib.pp_pack_rgb_to_4(ctx.handle, x3.numel() // 3, _ptr(x3), _ptr(x4)), ctx.handle, "pp_pack_rgb_to_4")
 

@@ -34,6 +34,23 @@ AnchorParameters.default = AnchorParameters(
 )
 
 
+# five-level variant for __create_pyramid_features (P3..P7): the RetinaNet sizes / strides the reference inherits from
+# keras-retinanet (its own default above is cut down to the three levels of the sparse pyramid)
+AnchorParameters.p3p7 = AnchorParameters(
+    sizes=[32, 64, 128, 256, 512],
+    strides=[8, 16, 32, 64, 128],
+    ratios=np.array([0.5, 1, 2], np.float32),
+    scales=np.array([2 ** 0, 2 ** (1.0 / 3.0), 2 ** (2.0 / 3.0)], np.float32),
+)
+# the commented-out dataset presets of utils/anchors.py:55-69 (4 scales -> 12 anchors per cell)
+AnchorParameters.ycbv = AnchorParameters(
+    sizes=[48, 96, 192], strides=[8, 16, 32], ratios=np.array([0.5, 1, 2], np.float32),
+    scales=np.array([2 ** 0, 2 ** (1.0 / 3.0), 2 ** (2.0 / 3.0), 2 ** 1], np.float32))
+AnchorParameters.homebrewed = AnchorParameters(
+    sizes=[24, 64, 160], strides=[8, 16, 32], ratios=np.array([0.5, 1, 2], np.float32),
+    scales=np.array([2 ** 0, 2 ** (1.0 / 3.0), 2 ** (2.0 / 3.0), 2 ** 1], np.float32))
+
+
 def generate_anchors(base_size=16, ratios=None, scales=None):
     if ratios is None:
         ratios = AnchorParameters.default.ratios

@@ -336,3 +336,64 @@ def test_inference_batch_decode_and_compaction(ctx):
             assert np.array_equal(idx[b, c, : cnt[b, c]], want[c])
     anc = OA.anchors_for_shape_f32((H, W))
     assert np.array_equal(box.cpu().numpy(), OA.box3d_transform_inv_f32(anc[None], eng.out_box.cpu().numpy()))
+
+
+@pytest.mark.parametrize("pyramid,anchors", [("p3p7", "p3p7"), ("fpn", "ycbv")])
+def test_pyramid_variants_vs_oracle_f64(ctx, pyramid, anchors):
+    """__create_pyramid_features (P3..P7, ReLU before the P7 conv, 5-level heads) and __create_FPN with the
+    12-anchor YCB-V preset: forward outputs, decode and one backward pass against the float64 restatement."""
+    from oracle import anchors_np as OA
+    from oracle import model_torch as MT
+    from pyrapose_amd import arch
+    from pyrapose_amd.engine import Engine
+    from pyrapose_amd.utils import anchors as UA
+    B, H, W, C = 2, 136, 200, 6
+    ap = getattr(UA.AnchorParameters, anchors)
+    A = ap.num_anchors()
+    rng = np.random.default_rng(31)
+    Wt = arch.init_weights(C, seed=17, pyramid=pyramid, num_anchors=A)
+    x = synth_input(rng, B, H, W)
+    eng = Engine(ctx, C, B, H, W, weights=Wt, train=True, pyramid=pyramid, anchor_params=ap)
+    levels = list(arch.PYRAMID_LEVELS[pyramid])
+    assert eng.N == sum(-(-H // 2 ** l) * -(-W // 2 ** l) for l in levels) * A
+    y_box, y_cls, y_mask = random_targets(rng, B, eng.N, eng.M3, C)
+    eng.set_targets(*[torch.from_numpy(a).cuda() for a in (y_box, y_cls, y_mask)])
+    eng.forward(torch.from_numpy(x).cuda())
+    reg, cls, mask = [t.cpu().numpy() for t in eng.export_outputs()]
+    losses_ref, g_ref, ref = MT.loss_and_grads(Wt, x, y_box, y_cls, y_mask, C, torch.float64, pyramid=pyramid)
+    assert rel(reg, ref["3Dbox"].detach().numpy()) < TOL
+    assert rel(cls, ref["cls"].detach().numpy()) < TOL
+    assert rel(mask, ref["mask"].detach().numpy()) < TOL
+    # decode against the float32 anchors of the same parameters
+    params = dict(sizes=ap.sizes, strides=ap.strides, ratios=ap.ratios, scales=ap.scales)
+    anc = OA.anchors_for_shape_f32((H, W), pyramid_levels=levels, params=params)
+    box = ops_box3d(eng, reg)
+    assert np.array_equal(box, OA.box3d_transform_inv_f32(anc[None], reg))
+    eng.loss_and_backward()
+    P = eng.params
+    eng.opt.grad_norm(P.w_master, P.grad, P.scales, eng.gnorm_sq, eng.loss_sums[3:4])
+    got = eng.losses()
+    for k in ("3Dbox", "cls", "mask", "l2"):
+        assert abs(got[k] - losses_ref[k]) <= 1e-4 * max(abs(losses_ref[k]), 1e-3), (k, got[k], losses_ref[k])
+    g_eff = P.export(P.grad)
+    sc = P.scales.cpu().numpy()
+    num = den = 0.0
+    for key, gr in g_ref.items():
+        layer, kind = key.split("/")
+        s = P.specs[layer]
+        g = g_eff[key].astype(np.float64)
+        if kind == "kernel":
+            if s.bn:
+                off = P.entries[key]["scale_off"]
+                g = g * sc[off: off + s.cout][None, None, None, :]
+            if s.l2:
+                g = g + 2 * s.l2 * Wt[key]
+        n_, d_ = float(((g - gr.numpy()) ** 2).sum()), float((gr.numpy() ** 2).sum())
+        num += n_; den += d_
+        assert np.sqrt(n_ / max(d_, 1e-300)) < 8e-2, (key, np.sqrt(n_ / max(d_, 1e-300)))
+    assert np.sqrt(num / den) < 3e-2, np.sqrt(num / den)
+
+
+def ops_box3d(eng, reg):
+    from pyrapose_amd import ops
+    return ops.box3d_decode(eng.ctx, eng.anchors_device_f32(), torch.from_numpy(reg).cuda()).cpu().numpy()
