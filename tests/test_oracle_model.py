@@ -108,3 +108,28 @@ def test_adam_clipnorm_semantics():
     lr_t = 1e-3 * math.sqrt(1 - 0.999) / (1 - 0.9)
     want = -lr_t * (0.1 * gc) / (np.sqrt(0.001 * gc ** 2) + 1e-7)
     np.testing.assert_allclose(new_w["a/kernel"].numpy(), want, rtol=1e-12)
+
+
+def test_pyramid_variants_shapes_and_relu_gate():
+    """__create_pyramid_features (retinanet.py:134-157): five levels, N = sum(ceil(H/2^l) * ceil(W/2^l)) * A, and P7 sees
+    ReLU(P6): with a P6 conv that outputs only negative values every P7 feature equals the P7 bias."""
+    import numpy as np
+    import torch
+    from oracle import model_torch as MT
+    from pyrapose_amd import arch
+    C, H, W = 3, 136, 200
+    Wt = arch.init_weights(C, seed=2, pyramid="p3p7")
+    x = np.random.default_rng(0).standard_normal((1, H, W, 3)).astype(np.float32) * 50
+    out = MT.forward(Wt, x, C, torch.float32, pyramid="p3p7")
+    n = sum(-(-H // 2 ** l) * -(-W // 2 ** l) for l in (3, 4, 5, 6, 7)) * 9
+    assert out["3Dbox"].shape == (1, n, 16) and out["cls"].shape == (1, n, C)
+    assert out["mask"].shape == (1, -(-H // 8) * -(-W // 8), C)
+    Wt2 = dict(Wt)
+    Wt2["P6_con/kernel"] = np.zeros_like(Wt["P6_con/kernel"])
+    Wt2["P6_con/bias"] = np.full_like(Wt["P6_con/bias"], -1.0)
+    Wt2["P7_con/bias"] = np.linspace(-1, 1, 256).astype(np.float32)
+    C2, C3, C4, C5 = MT.resnet50(torch.from_numpy(x).permute(0, 3, 1, 2), Wt2, torch.float32)
+    feats = MT.pyramid_features(C3, C4, C5, Wt2, torch.float32)
+    assert len(feats) == 5 and torch.all(feats[3] == -1.0)
+    assert torch.allclose(feats[4], torch.from_numpy(Wt2["P7_con/bias"]).view(1, -1, 1, 1).expand_as(feats[4]))
+    assert len(MT.pyramid_features(C3, C4, C5, Wt2, torch.float32, with_p6p7=False)) == 3
