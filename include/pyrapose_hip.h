@@ -258,6 +258,16 @@ int pp_filter_detections_batch(pp_ctx* ctx, int n_img, int n, int n_class, const
                                const float* scores, float score_thr, float iou_thr, int max_det, void* workspace,
                                float* out_boxes, float* out_boxes3d, float* out_scores, int* out_labels);
 
+/* ---- pose-error metrics of the evaluation tail -------------------------------------------------------
+ * utils/pose_error.py:210-228 add() and :231-246 adi(), as called at utils/linemod_eval.py:525-531 (decision:
+ * error < 0.1 * model diameter).  float64; n_pose (R, t) pairs against ONE model point set pts [n_pts,3];
+ * R row-major [n_pose,3,3], t [n_pose,3]; out [n_pose].  workspace >= pp_pose_error_workspace_bytes. */
+size_t pp_pose_error_workspace_bytes(int n_pose, int n_pts);
+int pp_pose_add_f64(pp_ctx* ctx, int n_pose, int n_pts, const double* pts, const double* R_est, const double* t_est,
+                    const double* R_gt, const double* t_gt, void* workspace, double* out);
+int pp_pose_adi_f64(pp_ctx* ctx, int n_pose, int n_pts, const double* pts, const double* R_est, const double* t_est,
+                    const double* R_gt, const double* t_gt, void* workspace, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,7 +114,10 @@ _SIGS = {
     "pp_box3d_decode": (_i, [_p, _i, _i, _p, _p, _p]),
     "pp_score_threshold_compact": (_i, [_p, _i, _i, _i, _p, _f, _i, _p, _p]),
     "pp_filter_workspace_bytes": (_sz, [_i, _i, _i]),
+    "pp_pose_error_workspace_bytes": (_sz, [_i, _i]),
     "pp_filter_detections": (_i, [_p, _i, _i, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p]),
+    "pp_pose_add_f64": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "pp_pose_adi_f64": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "pp_filter_detections_batch": (_i, [_p, _i, _i, _i, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p]),
 }
 

@@ -336,3 +336,17 @@ def filter_detections(ctx, boxes, boxes3d, scores, score_thr=0.05, iou_thr=0.5, 
     check(lib.pp_filter_detections(ctx.handle, N, Cc, _ptr(boxes), _ptr(boxes3d), _ptr(scores), score_thr, iou_thr, max_det,
                                    _ptr(ws), _ptr(ob), _ptr(o3), _ptr(osc), _ptr(ol)), ctx.handle, "pp_filter_detections")
     return ob, o3, osc, ol
+
+
+def pose_errors(ctx, pts, R_est, t_est, R_gt, t_gt, symmetric=False):
+    """ADD (symmetric=False) or ADD-S / ADI (True) of n poses against one model: cuda float64 tensors
+    pts [n_pts,3], R_* [n,3,3], t_* [n,3] -> float64 [n]."""
+    n, n_pts = R_est.shape[0], pts.shape[0]
+    args = [t.contiguous() for t in (pts, R_est, t_est, R_gt, t_gt)]
+    for t in args:
+        assert t.dtype == torch.float64 and t.is_cuda
+    ws = torch.empty((max(1, lib.pp_pose_error_workspace_bytes(n, n_pts)),), dtype=torch.uint8, device="cuda")
+    out = torch.empty((n,), dtype=torch.float64, device="cuda")
+    fn = lib.pp_pose_adi_f64 if symmetric else lib.pp_pose_add_f64
+    check(fn(ctx.handle, n, n_pts, *[_ptr(t) for t in args], _ptr(ws), _ptr(out)), ctx.handle, "pp_pose_adi_f64" if symmetric else "pp_pose_add_f64")
+    return out
