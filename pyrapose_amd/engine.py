@@ -30,10 +30,13 @@ def tf_same_pad(n_in, k, s):
 
 class Op(object):
     """One C-ABI launch of the plan: `fn()` enqueues it on the ctx stream."""
-    __slots__ = ("fn", "kind", "name", "flops", "wrange", "lane")
+    __slots__ = ("fn", "kind", "name", "flops", "wrange", "lane", "reads", "waits", "done_ev")
 
     def __init__(self, fn, kind, name="", flops=0.0, wrange=None, lane=0):
         self.fn, self.kind, self.name, self.flops, self.wrange, self.lane = fn, kind, name, flops, wrange, lane
+        self.reads = ()      # forward plan: the activations this launch reads ...
+        self.waits = ()      # ... -> events of their producers on OTHER lanes, awaited before the launch
+        self.done_ev = None  # recorded after the launch when a consumer on another lane needs it
 
     def __call__(self):
         self.fn()
@@ -49,6 +52,7 @@ class Act(object):
         self.t = t if t is not None else torch.empty((self.rows, self.ld), dtype=torch.float32, device="cuda")
         self.needs_grad, self.relu = needs_grad, relu
         self.contribs = []
+        self.prod_ops = []  # forward launches that write this tensor (an alias lists those of its parts)
         self.pl = None  # (hi, lo) int16 [rows, ld]: the same matrix pre-split into bf16 planes (bf16x3 mode, conv-produced)
 
     def rowspace(self):
@@ -224,6 +228,7 @@ class Engine(object):
             for c in self.ctxs:
                 c.set_workspace(ws_mb << 20)
         self._lane = 0
+        self.trunk_lanes = os.environ.get("PP_TRUNK_LANES", "1") != "0"  # backbone shortcut / FPN level 4-5 chains on lane 1
         self.acts = OrderedDict()
         self.step_count = 0
         self._build_forward()
@@ -253,6 +258,42 @@ class Engine(object):
         a = Act(name, self.B, shapes, C, ld, t, needs_grad, relu)
         self.acts[name] = a
         return a
+
+    def _on(self, lane):
+        """`with self._on(1): ...` builds the enclosed launches on side lane 1 (lane 0 when PP_LANES=1)"""
+        eng = self
+
+        class _Lane(object):
+            def __enter__(self_):
+                self_.prev = eng._lane
+                eng._lane = (lane % eng.n_lanes) if eng.trunk_lanes else eng._lane
+
+            def __exit__(self_, *exc):
+                eng._lane = self_.prev
+        return _Lane()
+
+    def _push(self, op, reads, writes):
+        """append a forward launch and record its dataflow (lane dependencies are derived from it, _link_lanes)"""
+        op.reads = tuple(a for a in reads if a is not None)
+        if writes is not None:
+            writes.prod_ops.append(op)
+        self.fwd_ops.append(op)
+        return op
+
+    def _link_lanes(self):
+        """A launch waits for the producers of its inputs that were enqueued on another lane (HIP events, created once)."""
+        pos = {id(o): i for i, o in enumerate(self.fwd_ops)}
+        for i, op in enumerate(self.fwd_ops):
+            waits = []
+            for a in op.reads:
+                for p in a.prod_ops:
+                    assert pos[id(p)] < i, "forward plan out of order: %s reads %s" % (op.name, a.name)
+                    if p.lane != op.lane:
+                        if p.done_ev is None:
+                            p.done_ev = torch.cuda.Event()
+                        if p.done_ev not in waits:
+                            waits.append(p.done_ev)
+            op.waits = tuple(waits)
 
     def _conv(self, spec_name, x, out_name=None, relu=False, residual=None, out_t=None, out_ld=None, out_pl=None):
         s = self.params.specs[spec_name]
@@ -301,10 +342,11 @@ class Engine(object):
             if self._wants_planes(s):
                 x.conv3_consumers = getattr(x, "conv3_consumers", 0) + 1
             y.producer = s
-            self.fwd_ops.append(Op(lambda: ops.conv_fwd3(ctx, desc, x.t, fh, fl, b, rt, relu, y.t, x.pl, y.pl), "conv_fwd", spec_name,
-                                   flops, None, lane))
+            self._push(Op(lambda: ops.conv_fwd3(ctx, desc, x.t, fh, fl, b, rt, relu, y.t, x.pl, y.pl), "conv_fwd", spec_name,
+                          flops, None, lane), (x, residual), y)
         else:
-            self.fwd_ops.append(Op(lambda: ops.conv_fwd(ctx, desc, x.t, w, b, rt, relu, y.t), "conv_fwd", spec_name, flops, None, lane))
+            self._push(Op(lambda: ops.conv_fwd(ctx, desc, x.t, w, b, rt, relu, y.t), "conv_fwd", spec_name, flops, None, lane),
+                       (x, residual), y)
         self.graph_ops.append(dict(kind="conv", spec=s, x=x, y=y, residual=residual, desc=desc, w=w, flops=flops, planes=pl))
         return y
 
@@ -317,13 +359,13 @@ class Engine(object):
         ctx = self.ctx
         self.x_in = torch.zeros((B, H, W, 3), dtype=torch.float32, device="cuda")
         x4 = self._new_act("input4", [(H, W)], 4)
-        self.fwd_ops.append(Op(lambda: ops.pack_rgb_to_4(ctx, self.x_in, x4.t), "pointwise", "pack_rgb"))
+        self._push(Op(lambda: ops.pack_rgb_to_4(ctx, self.x_in, x4.t), "pointwise", "pack_rgb"), (), x4)
         y = self._conv("conv1", x4, relu=True)
         (h1, w1) = y.shapes[0]
         ph, pw = (h1 + 1) // 2, (w1 + 1) // 2
         pool = self._new_act("pool1", [(ph, pw)], 64)
         c1 = y
-        self.fwd_ops.append(Op(lambda: ops.maxpool3x3s2(ctx, B, h1, w1, 64, c1.t, ph, pw, pool.t), "pointwise", "pool1"))
+        self._push(Op(lambda: ops.maxpool3x3s2(ctx, B, h1, w1, 64, c1.t, ph, pw, pool.t), "pointwise", "pool1"), (c1,), pool)
         self.graph_ops.append(dict(kind="stop"))
         y = pool
         blocks = arch.BACKBONE_BLOCKS[self.backbone]
@@ -334,7 +376,11 @@ class Engine(object):
                 pre = "res%d%s" % (stage + 2, arch.block_name(stage, block, numerical[stage]))
                 a = self._conv(pre + "_branch2a", y, relu=True)
                 b = self._conv(pre + "_branch2b", a, relu=True)
-                sc = self._conv(pre + "_branch1", y) if block == 0 else y
+                if block == 0:
+                    with self._on(1):  # the projection shortcut runs beside the 2a -> 2b chain
+                        sc = self._conv(pre + "_branch1", y)
+                else:
+                    sc = y
                 y = self._conv(pre + "_branch2c", b, out_name=pre, relu=True, residual=sc)
             stage_out.append(y)
         C3, C4, C5 = stage_out[1], stage_out[2], stage_out[3]
@@ -367,6 +413,7 @@ class Engine(object):
                 if i < len(c):
                     mixed.append(c[i])
         self.fwd_ops = trunk + mixed
+        self._link_lanes()
         # planes nobody reads are not written (the forward closures read .pl at call time)
         for a in self.acts.values():
             if a.pl is not None and not getattr(a, "conv3_consumers", 0) and a.pl[0]._base is None:  # (P4/P5 write slices of pyr's)
@@ -388,27 +435,31 @@ class Engine(object):
 
     def _build_sparse_fpn(self, C3, C4, C5):
         """__create_sparceFPN (models/retinanet.py:180-214)"""
+        # two chains: level 3 on lane 0, levels 4/5 on lane 1 (their launches are small: 150-600 workgroups each)
         L3 = self._conv("fpn_lat3", C3)
-        L4 = self._conv("fpn_lat4", C4)
-        L5 = self._conv("fpn_lat5", C5)
-        S4 = self._upadd("fpn_sum4", L5, L4)
+        with self._on(1):
+            L4 = self._conv("fpn_lat4", C4)
+            L5 = self._conv("fpn_lat5", C5)
+            S4 = self._upadd("fpn_sum4", L5, L4)
+            M4 = self._conv("fpn_mid4", S4)
         S3 = self._upadd("fpn_sum3", L4, L3)
-        M4 = self._conv("fpn_mid4", S4)
         M3 = self._conv("fpn_mid3", S3)
         D3 = self._conv("fpn_down3", M3)
         F3 = self._add("fpn_fin3", [M3, L3])
         lv = [L3.shapes[0], L4.shapes[0], L5.shapes[0]]
         pyr_t, pyr_pl, rows, sl, spl = self._pyramid_buffer(lv)
         P3 = self._conv("P3", F3, out_t=sl[0], out_pl=spl[0])
-        F4 = self._add("fpn_fin4", [D3, M4, L4])
-        D4 = self._conv("fpn_down4", M4)
-        P4 = self._conv("P4", F4, out_t=sl[1], out_pl=spl[1])
-        F5 = self._add("fpn_fin5", [D4, L5])
-        P5 = self._conv("P5", F5, out_t=sl[2], out_pl=spl[2])
+        with self._on(1):
+            F4 = self._add("fpn_fin4", [D3, M4, L4])
+            D4 = self._conv("fpn_down4", M4)
+            P4 = self._conv("P4", F4, out_t=sl[1], out_pl=spl[1])
+            F5 = self._add("fpn_fin5", [D4, L5])
+            P5 = self._conv("P5", F5, out_t=sl[2], out_pl=spl[2])
         needs = self.train
         pyr = self._new_act("pyramid", lv, 256, 256, needs, False, pyr_t)
         pyr.pl = pyr_pl
         pyr.producer = getattr(P3, "producer", None)
+        pyr.prod_ops = [o for part in (P3, P4, P5) for o in part.prod_ops]
         self.graph_ops.append(dict(kind="alias", y=pyr, parts=[P3, P4, P5], rows=rows))
         return pyr, P3
 
@@ -436,21 +487,25 @@ class Engine(object):
         pyr = self._new_act("pyramid", lv, 256, 256, self.train, False, pyr_t)
         pyr.pl = pyr_pl
         pyr.producer = getattr(P3, "producer", None)
+        pyr.prod_ops = [o for part in parts for o in part.prod_ops]
         self.graph_ops.append(dict(kind="alias", y=pyr, parts=parts, rows=rows))
         return pyr, P3
 
     def _relu(self, name, x):
         out = self._new_act(name, x.shapes, x.C, x.ld, x.needs_grad, True)
-        ctx = self.ctx
-        self.fwd_ops.append(Op(lambda: ops.relu_fwd(ctx, x.t, out.t), "pointwise", name))
+        lane = self._lane
+        ctx = self.ctxs[lane]
+        self._push(Op(lambda: ops.relu_fwd(ctx, x.t, out.t), "pointwise", name, lane=lane), (x,), out)
         self.graph_ops.append(dict(kind="relu", y=out, x=x))
         return out
 
     def _upadd(self, name, src, other):
         (sh, sw), (th, tw) = src.shapes[0], other.shapes[0]
         out = self._new_act(name, [(th, tw)], src.C, src.ld, src.needs_grad or other.needs_grad)
-        ctx, B = self.ctx, self.B
-        self.fwd_ops.append(Op(lambda: ops.upsample_add_fwd(ctx, B, sh, sw, th, tw, src.C, src.t, other.t, out.t), "pointwise", name))
+        lane, B = self._lane, self.B
+        ctx = self.ctxs[lane]
+        self._push(Op(lambda: ops.upsample_add_fwd(ctx, B, sh, sw, th, tw, src.C, src.t, other.t, out.t), "pointwise", name, lane=lane),
+                   (src, other), out)
         self.graph_ops.append(dict(kind="upadd", y=out, src=src, other=other))
         self._split_act(out)
         return out
@@ -459,15 +514,17 @@ class Engine(object):
         """FPN sums feed trainable 3x3 convs: give them planes with an explicit split launch (their producer is not a conv)."""
         if self.train and self.use_act_planes and act.ld % 8 == 0:
             act.pl = _new_planes(act.rows, act.ld)
-            ctx = self.ctx
-            self.fwd_ops.append(Op(lambda: ops.split_planes3(ctx, act.t, act.pl[0], act.pl[1]) if act.pl is not None else None,
-                                   "pointwise", "split:" + act.name))
+            lane = self._lane
+            ctx = self.ctxs[lane]
+            self._push(Op(lambda: ops.split_planes3(ctx, act.t, act.pl[0], act.pl[1]) if act.pl is not None else None,
+                          "pointwise", "split:" + act.name, lane=lane), (act,), act)
 
     def _add(self, name, ins):
         out = self._new_act(name, ins[0].shapes, ins[0].C, ins[0].ld, any(i.needs_grad for i in ins))
-        ctx = self.ctx
+        lane = self._lane
+        ctx = self.ctxs[lane]
         a, b, c = ins[0].t, ins[1].t, (ins[2].t if len(ins) > 2 else None)
-        self.fwd_ops.append(Op(lambda: ops.add_n(ctx, a, b, c, out.t), "pointwise", name))
+        self._push(Op(lambda: ops.add_n(ctx, a, b, c, out.t), "pointwise", name, lane=lane), ins, out)
         self.graph_ops.append(dict(kind="add", y=out, ins=ins))
         self._split_act(out)
         return out
@@ -623,12 +680,15 @@ class Engine(object):
     def forward(self, x=None):
         if x is not None:
             self.x_in.copy_(x)
-        side = list(range(1, self.n_lanes))
-        for i, f in enumerate(self.fwd_ops):
-            if i == self.fwd_fork:
-                self._fork(side)
-            f()
-        self._join(side)
+        streams = self.streams
+        for op in self.fwd_ops:
+            st = streams[op.lane]
+            for ev in op.waits:
+                st.wait_event(ev)
+            op.fn()
+            if op.done_ev is not None:
+                op.done_ev.record(st)
+        self._join(list(range(1, self.n_lanes)))
 
     def export_outputs(self):
         """Keras prediction-model outputs (models/retinanet.py:302-335): [boxes3D, cls probs, mask probs]."""
