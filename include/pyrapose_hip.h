@@ -152,6 +152,12 @@ int pp_add_n(pp_ctx* ctx, size_t n, const float* a, const float* b, const float*
 int pp_relu_fwd(pp_ctx* ctx, size_t n, const float* x, float* y);
 /* [n_img,h,w,3] -> [n_img,h,w,4] zero-padded channel (feeds conv1 as cin == 4) */
 int pp_pack_rgb_to_4(pp_ctx* ctx, size_t n_pixels, const float* x3, float* x4);
+/* utils/image.py:35-62 preprocess_image(mode='caffe') + preprocessing/generator.py:319-336 compute_inputs in one pass:
+ * images_u8 [n_img,H,W,3] uint8 (BGR as the reference reads them; image b occupies the upper-left sizes_hw[b] = (h, w)
+ * corner of the frame) -> x4 [n_img,H,W,4] float32 = pixel - (103.939, 116.779, 123.68) inside the image, 0 in the
+ * padding and in channel 3.  sizes_hw is a HOST array of 2*n_img ints (n_img <= 64). */
+int pp_preprocess_caffe_u8(pp_ctx* ctx, int n_img, int H, int W, const int* sizes_hw_host, const unsigned char* images_u8,
+                           float* x4);
 
 /* ---- head output export ---------------------------------------------------------------
  * Head convs write level-major matrices [rows][ld]; Keras concatenates the per-level reshapes on

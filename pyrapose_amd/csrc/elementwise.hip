@@ -184,6 +184,44 @@ extern "C" int pp_pack_rgb_to_4(pp_ctx* ctx, size_t n_pixels, const float* x3, f
   return PP_OK;
 }
 
+// ---- uint8 BGR batch -> caffe mean-subtracted, zero-padded, packed stem input (first piece) ----------
+// utils/image.py:35-62 preprocess_image(mode='caffe'): x.astype(float32); x[..., c] -= (103.939, 116.779, 123.68)[c]
+// preprocessing/generator.py:319-336 compute_inputs: images copied into the upper-left corner of a ZERO batch, i.e.
+// the padding stays 0.0 (it is not mean-subtracted).  sizes[b] = (h_b, w_b) of image b inside the [H, W] batch frame.
+struct U8Sizes { int hw[2 * 64]; };
+__global__ void preprocess_u8_kernel(int n_img, int H, int W, U8Sizes sz, const unsigned char* __restrict__ u8, float4* __restrict__ x4) {
+  const size_t n_pix = (size_t)n_img * H * W;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_pix; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H), b = (int)(i / ((size_t)W * H));
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y < sz.hw[2 * b] && x < sz.hw[2 * b + 1]) {
+      v.x = (float)u8[3 * i] - 103.939f;
+      v.y = (float)u8[3 * i + 1] - 116.779f;
+      v.z = (float)u8[3 * i + 2] - 123.68f;
+    }
+    x4[i] = v;
+  }
+}
+
+extern "C" int pp_preprocess_caffe_u8(pp_ctx* ctx, int n_img, int H, int W, const int* sizes_hw_host, const unsigned char* images_u8,
+                                      float* x4) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, n_img > 0 && n_img <= 64 && H > 0 && W > 0, PP_ERR_SHAPE, "pp_preprocess_caffe_u8: 1..64 images per call");
+  PP_CHECK_ARG(ctx, images_u8 && x4 && sizes_hw_host && pp_is_aligned16(x4), PP_ERR_ARG, "pp_preprocess_caffe_u8: null / unaligned tensor");
+  U8Sizes sz;
+  for (int b = 0; b < n_img; ++b) {
+    PP_CHECK_ARG(ctx, sizes_hw_host[2 * b] >= 0 && sizes_hw_host[2 * b] <= H && sizes_hw_host[2 * b + 1] >= 0 && sizes_hw_host[2 * b + 1] <= W,
+                 PP_ERR_SHAPE, "pp_preprocess_caffe_u8: image %d (%d x %d) does not fit the %d x %d batch frame", b, sizes_hw_host[2 * b],
+                 sizes_hw_host[2 * b + 1], H, W);
+    sz.hw[2 * b] = sizes_hw_host[2 * b];
+    sz.hw[2 * b + 1] = sizes_hw_host[2 * b + 1];
+  }
+  hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid_for((size_t)n_img * H * W, 256, ctx)), dim3(256), 0, ctx->stream, n_img, H, W, sz,
+                     images_u8, (float4*)x4);
+  PP_CHECK_LAUNCH(ctx, "pp_preprocess_caffe_u8");
+  return PP_OK;
+}
+
 // ---- head export: level-major [rows][ld] -> Keras (B, sum_l HW_l*A, V) ---------------------------
 struct ExportGeo {
   int n_seg, n_img;

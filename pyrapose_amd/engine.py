@@ -690,6 +690,21 @@ class Engine(object):
                 op.done_ev.record(st)
         self._join(list(range(1, self.n_lanes)))
 
+    def forward_u8(self, images_u8, sizes_hw=None):
+        """Forward from a uint8 BGR batch [B,H,W,3] on the device: mean subtraction, zero padding and channel packing run
+        in one kernel in place of the host-side preprocess_image / compute_inputs (4x less host->device traffic)."""
+        if sizes_hw is None:
+            sizes_hw = [(self.H, self.W)] * self.B
+        x4 = self.acts["input4"]
+        ops.preprocess_caffe_u8(self.ctx, images_u8, sizes_hw, x4.t)
+        skip = self.fwd_ops[0]
+        assert skip.name == "pack_rgb"
+        fn, skip.fn = skip.fn, (lambda: None)
+        try:
+            self.forward(None)
+        finally:
+            skip.fn = fn
+
     def export_outputs(self):
         """Keras prediction-model outputs (models/retinanet.py:302-335): [boxes3D, cls probs, mask probs]."""
         ctx = self.ctx

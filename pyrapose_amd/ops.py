@@ -165,6 +165,14 @@ def relu_fwd(ctx, x, y):
     check(lib.pp_relu_fwd(ctx.handle, x.numel(), _ptr(x), _ptr(y)), ctx.handle, "pp_relu_fwd")
 
 
+def preprocess_caffe_u8(ctx, images_u8, sizes_hw, x4):
+    """images_u8: cuda uint8 [B,H,W,3]; sizes_hw: B (h, w) pairs; x4: cuda float32 [B*H*W, 4] (the engine's stem input)."""
+    Bn, H, W, _ = images_u8.shape
+    assert images_u8.dtype == torch.uint8 and images_u8.is_contiguous()
+    arr = (C.c_int * (2 * Bn))(*[int(v) for hw in sizes_hw for v in hw])
+    check(lib.pp_preprocess_caffe_u8(ctx.handle, Bn, H, W, arr, _ptr(images_u8), _ptr(x4)), ctx.handle, "pp_preprocess_caffe_u8")
+
+
 def pack_rgb_to_4(ctx, x3, x4):
     check(lib.pp_pack_rgb_to_4(ctx.handle, x3.numel() // 3, _ptr(x3), _ptr(x4)), ctx.handle, "pp_pack_rgb_to_4")
 

@@ -114,3 +114,40 @@ def test_layers_and_backend_mirrors():
     src = torch.randn((1, 17, 23, 8), device="cuda")
     up = layers.UpsampleLike()([src, torch.zeros((1, 34, 45, 8), device="cuda")])
     assert up.shape == (1, 34, 45, 8)
+
+
+def test_preprocess_u8_matches_reference_preprocessing():
+    """pp_preprocess_caffe_u8 == preprocess_image(mode='caffe') + compute_inputs zero padding (utils/image.py:35-62,
+    preprocessing/generator.py:319-336), bit for bit, and Engine.forward_u8 == Engine.forward on the same batch."""
+    import numpy as np
+    import torch
+    from pyrapose_amd import ops
+    from pyrapose_amd.engine import Engine
+    from pyrapose_amd.runtime import default_context
+    ctx = default_context()
+    rng = np.random.default_rng(8)
+    B, H, W = 3, 64, 96
+    sizes = [(64, 96), (50, 96), (64, 71)]
+    u8 = np.zeros((B, H, W, 3), np.uint8)
+    want = np.zeros((B, H, W, 3), np.float32)
+    for b, (h, w) in enumerate(sizes):
+        img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        u8[b, :h, :w] = img
+        x = img.astype(np.float32)           # the reference's three statements
+        x[..., 0] -= 103.939
+        x[..., 1] -= 116.779
+        x[..., 2] -= 123.68
+        want[b, :h, :w] = x
+    x4 = torch.full((B * H * W, 4), float("nan"), dtype=torch.float32, device="cuda")
+    ops.preprocess_caffe_u8(ctx, torch.from_numpy(u8).cuda(), sizes, x4)
+    got = x4.cpu().numpy().reshape(B, H, W, 4)
+    assert np.array_equal(got[..., :3], want) and not got[..., 3].any()
+    eng = Engine(ctx, 5, B, H, W, train=False)
+    eng.forward(torch.from_numpy(want).cuda())
+    a = [t.clone() for t in eng.export_outputs()]
+    eng.forward_u8(torch.from_numpy(u8).cuda(), sizes)
+    b_ = eng.export_outputs()
+    for p, q in zip(a, b_):
+        assert torch.equal(p, q)
+    with pytest.raises(ValueError):
+        ops.preprocess_caffe_u8(ctx, torch.from_numpy(u8).cuda(), [(65, 96)] * B, x4)
