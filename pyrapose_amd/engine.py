@@ -7,7 +7,6 @@ Backward = reverse-mode over the same op list with the sum-of-consumers and the 
 into the last data-gradient launch of each tensor (see DESIGN.md §Backward dataflow).
 Loss / optimizer = bin/train.py:95-102.
 """
-import math
 import os as _os
 from collections import OrderedDict
 
@@ -715,7 +714,6 @@ class Engine(object):
 
     def anchors_device_f32(self):
         if self.anchors_f32 is None:
-            from .utils import anchors as ua
             p = self.anchor_params
             base = np.stack([ops.generate_base_anchors(sz, p.ratios, p.scales) for sz in p.sizes[: len(self.levels)]])
             self.anchors_f32 = ops.anchors_shift(self.ctx, self.levels, p.strides[: len(self.levels)], base, torch.float32)

@@ -13,7 +13,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from .. import arch, losses as losses_mod, optimizers
+from .. import arch, optimizers
 from ..engine import Engine
 from ..runtime import default_context
 

@@ -8,7 +8,6 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _lib
 from ._lib import ConvDesc, ParamDesc, RowSpace, check, lib
 
 

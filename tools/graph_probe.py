@@ -1,7 +1,6 @@
 """Does capturing the forward plan in a HIP graph shorten it?  (eager launches vs graph replay, same kernels)"""
 import os
 import sys
-import time
 
 import torch
 

@@ -1,4 +1,4 @@
-import sys, os, time
+import sys, time
 sys.path.insert(0, '/root/repo')
 import torch
 from pyrapose_amd import ops
