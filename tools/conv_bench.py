@@ -33,6 +33,11 @@ SHAPES = {
     "r2t": (13, [(64, 64)], 512, 512, 3, 1, 1),    # 2 rounds + 8 %
     "occ4": (8, [(64, 64)], 512, 512, 3, 1, 1),
     "occ2": (4, [(64, 64)], 512, 512, 3, 1, 1),
+    "t32": (8, [(15, 20)], 32, 256, 1, 1, 0),       # fixed-cost probes: 2400 rows, 1 / 8 / 32 k-steps
+    "t256": (8, [(15, 20)], 256, 256, 1, 1, 0),
+    "t1024": (8, [(15, 20)], 1024, 256, 1, 1, 0),
+    "u32": (8, [(60, 80)], 32, 256, 1, 1, 0),       # 38400 rows, 1 / 8 k-steps
+    "u256": (8, [(60, 80)], 256, 256, 1, 1, 0),
     "down3": (8, [(60, 80)], 256, 256, 3, 2, 0),    # fpn_down3: 3x3 stride 2 'same' (pad_t = pad_l = 0)
     "down4": (8, [(30, 40)], 256, 256, 3, 2, 0),
     "r5a1": (8, [(30, 40)], 1024, 2048, 1, 2, 0),   # res5a_branch1: 1x1 stride 2
