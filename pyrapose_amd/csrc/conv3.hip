@@ -337,6 +337,9 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, int voff, 
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// Measured and NOT kept: walking the grid column-tile-major per XCD (one column tile's 2.4 MB of weight planes resident in
+// each 4 MiB L2, activations re-read by four XCDs): 2-5 % slower on the head shapes than the row-tile-major order -- the
+// 3x3 gather re-reads its activation rows nine times, so keeping THEM in L2 matters more than the weights.
 // Measured and NOT kept: the same loop on v_mfma_f32_16x16x32_bf16 (48 instead of 24 MFMAs per step, lane = (row, octet)
 // staging map, un-rotated image): bit-identical results, 20 % slower on every head shape (255-295 vs 325-355 TFLOP/s).
 template <int TM, int TN, bool AP, bool OP, bool SC = false>
