@@ -36,6 +36,18 @@ ALGO_GFLOP_PER_IMAGE = {(13, 480, 640): 683.2}  # BASELINE.md §3 (fwd 234.2 + b
 EVENT_EVERY = 4  # per-launch HIP events on steps 0, 4, 8, ... of the timed region
 
 
+def measured_peak(mode, achieved):
+    """the box-measured denominator next to the spec peak (profiles/r01_peaks.json, tools/ubench/peaks.hip)"""
+    path = os.path.join(ROOT, "profiles", "r01_peaks.json")
+    if mode != "bf16x3" or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        pk = json.load(f)
+    m = pk["bf16_mfma_tflops_with_lds_reads"]
+    return {"bf16_mfma_tflops_sustained_random_data": pk["bf16_mfma_tflops_registers"], "with_lds_fragment_reads": m,
+            "mfma_issue_frac_of_measured": achieved * 3 / m, "source": "profiles/r01_peaks.json (tools/ubench/peaks.hip, 20 ms launches)"}
+
+
 def synth_batch(B, H, W, C, seed):
     """images uint8 U[0,255] - caffe means; K~U{1..3} boxes, sides U[40,160]."""
     rng = np.random.default_rng(seed)
@@ -250,6 +262,7 @@ def main():
                     "mfma_flops_per_algorithmic_flop": 3 if mode == "bf16x3" else 1,
                     "mfma_issue_frac": roof["achieved"] * (3 if mode == "bf16x3" else 1) / peak,
                     "vs_f32_mfma_peak_157.3": roof["achieved"] / PEAK_F32_MFMA_TFLOPS,
+                    "measured_peak": measured_peak(mode, roof["achieved"]),
                     "dominant": roof["dominant"], "conv_share_of_step": roof["conv_share_of_step"], "lanes": roof["lanes"],
                     "per_kernel": roof["per_kernel"]}
 
