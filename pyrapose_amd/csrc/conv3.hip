@@ -337,6 +337,12 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, int voff, 
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// Measured and NOT kept (tools/conv_bench.py --shape r3 = exactly three rounds of workgroups, 128x128 tile): a 64-deep k-step
+// (twice the MFMAs per barrier pair, 2 workgroups/CU) and register double-buffering of the staged tiles (loads issued two
+// steps ahead, 190 VGPRs, 2 workgroups/CU) both land on the same 340-355 TFLOP/s as this loop; dependent MFMAs on one
+// accumulator issue back to back at full rate (tools/ubench/mfma_dep.hip).  Ablations of this loop: without global loads
+// +30 %, without the f32->bf16 conversion +17 %, with the gathered operand loaded for one tap in nine +12 %, MFMA +
+// fragment reads alone 530 TFLOP/s: the staging of the SAME activation rows for each of the nine taps is what is left.
 // Measured and NOT kept: walking the grid column-tile-major per XCD (one column tile's 2.4 MB of weight planes resident in
 // each 4 MiB L2, activations re-read by four XCDs): 2-5 % slower on the head shapes than the row-tile-major order -- the
 // 3x3 gather re-reads its activation rows nine times, so keeping THEM in L2 matters more than the weights.
