@@ -60,7 +60,7 @@ __device__ __forceinline__ int div_small(int a, int b, float rcp_b, int* rem) {
 }
 
 // ---- epilogue through LDS (see conv.hip), shared by both main loops ----
-template <int TM, int TN, bool OP, int GOP = 1, bool SC = false>
+template <int TM, int TN, bool OP, int GOP = 1, bool SC = false, bool XR = false>
 __device__ __forceinline__ void epilogue3(const IgemmParams& p, floatx16 (&acc)[TM][TN], uint4* smem, int m0, int n0, int tid, int wm,
                                           int wn, int il, int h, const float* __restrict__ g_bias,
                                           const float* __restrict__ g_addend, const float* __restrict__ g_mask,
@@ -107,7 +107,7 @@ __device__ __forceinline__ void epilogue3(const IgemmParams& p, floatx16 (&acc)[
             int mo[G];  // row of the output / addend / mask tensors (SC: the class row scattered into the full grid)
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-              const int m = min(base_row + e_r + RPI * (s0 + g), m_last);
+              const int m = XR ? max(min(base_row + e_r + RPI * (s0 + g), m_last), 0) : min(base_row + e_r + RPI * (s0 + g), m_last);
               mo[g] = m;
               if (SC) {
                 const int hw = p.seg[0].OH * p.seg[0].OW;
@@ -131,7 +131,9 @@ __device__ __forceinline__ void epilogue3(const IgemmParams& p, floatx16 (&acc)[
                 v.z = mk[g].z > 0.f ? v.z : 0.f; v.w = mk[g].w > 0.f ? v.w : 0.f;
               }
               if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-              if (m <= m_last) {
+              // XR (igemm3x): tile rows 0 and BM - 1 are halo rows that the neighbouring tiles own
+              const int trow = hm * 32 * TM + a0 * 32 + row;
+              if (m <= m_last && (!XR || (trow >= 1 && trow <= 64 * TM - 2))) {
                 if (!OP || g_out != nullptr) *reinterpret_cast<float4*>(g_out + (long long)mo[g] * p.ld_out + co) = v;
                 if (OP) {  // the consumer convs read their operand pre-split: split once here instead of per tile
                   uint2 oh, ol;
@@ -545,6 +547,241 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
   epilogue3<TM, TN, OP, 4, SC>(p, acc, smem, m0, n0, tid, wm, wn, il, h, g_bias, g_addend, g_mask, g_out, g_ohi, g_olo);
 }
 
+// ---- igemm3x: 3-wide stride-1 "same" convolutions with the gathered tile shared by the three taps of a kernel row ----
+// For a fixed kernel row ty the source pixel of output row m at tap tx is (m + dy * W(m)) + dx with dx = off_x + tx * tsign
+// in {-1, 0, 1}: the tile of tap dx is the tile of dx = 0 shifted by one row.  The workgroup stages its BM rows once per
+// (ty, 32-channel chunk) and the three taps read their fragments at row offsets -1, 0, +1; so that every output row finds
+// both neighbours inside the tile, consecutive tiles overlap by two rows: a tile covers output rows m0 .. m0 + BM - 1 but
+// only writes the BM - 2 inner ones (1.6 % of the MFMAs are spent on the two edge rows).  A row shifted across an
+// image-row / image / pyramid-level boundary lands on the wrong pixel exactly where the tap is padding: the per-lane
+// tap-validity bit zeroes that fragment.  Global loads, f32->bf16 conversions and LDS writes of the gathered operand drop
+// to a third.  Loop order: ty, channel chunk, tx (unrolled: the body of each tx is one basic block).
+// Conditions (host-checked): kw == 3, stride 1, source space == enumerated space (SH == OH, SW == OW, same row offsets),
+// f32 source, no planes / scatter.
+template <int TM, int TN>
+__global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3x_kernel(
+    const IgemmParams p, const void* __restrict__ g_a, unsigned a_bytes, const void* __restrict__ g_whi, const void* __restrict__ g_wlo,
+    unsigned w_bytes, const float* __restrict__ g_bias, const float* __restrict__ g_addend, const float* __restrict__ g_mask,
+    float* __restrict__ g_out, int w_rows, int w_ld8, int splits, float* __restrict__ g_ws) {
+  constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, NO = BK / 8;
+  constexpr int SMEM_U4 = 2 * NO * (BM + BN);
+  __shared__ __attribute__((aligned(16))) uint4 smem[SMEM_U4];
+  uint4* Ahi = smem;
+  uint4* Alo = Ahi + NO * BM;
+  uint4* Bhi = Alo + NO * BM;
+  uint4* Blo = Bhi + NO * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lbs = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int split = lbs % splits, lb = lbs / splits;
+  const int tile_n = lb % p.n_tiles_n, tile_m = lb / p.n_tiles_n;
+  const int m0 = tile_m * (BM - 2) - 1, n0 = tile_n * BN;  // tile row j <-> output row m0 + j; rows 0 and BM - 1 are halo only
+  const int oct = tid & 3, r0 = tid >> 2;
+  const int il = lane & 31, h = lane >> 5;
+  const int n_chunks = p.Cred / BK;
+  const int all_groups = p.kh * n_chunks;  // one group = the three taps of (ty, chunk)
+  const int g_begin = (int)((long long)all_groups * split / splits), g_end = (int)((long long)all_groups * (split + 1) / splits);
+
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_a), 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_whi), 0, w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_wlo), 0, w_bytes, 0x00020000);
+
+  // staged rows r0 + 64 * i: byte offset of the dx = 0 source pixel at ty = 0, row pitch (low 4 bits: source row y + dy exists, per ty)
+  int s_base[TM], s_pitch[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int q = m0 + r0 + 64 * i;
+    const RowPos r = decode_row(p, q < 0 ? 0 : q);
+    const bool ok = q >= 0 && r.ok;
+    const int x = r.xbase - p.off_x;  // dx = 0 <=> the output cell's own column
+    s_base[i] = ((r.rowbase + r.ybase * r.SW + x) * p.ld_src + 8 * oct) * 4;
+    int v = 0;
+    for (int ty = 0; ty < p.kh; ++ty)
+      if (ok && (unsigned)(r.ybase + ty * p.tsign) < (unsigned)r.SH) v |= 1 << ty;
+    s_pitch[i] = (p.tsign * r.SW * p.ld_src * 4) | v;  // ld_src % 4 == 0 -> the pitch is a multiple of 16
+  }
+  // fragment rows of this lane: wm * 32 * TM + a * 32 + il -> validity bit per tap (9 bits each, two rows per register)
+  unsigned f_valid = 0;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const int q = m0 + wm * 32 * TM + a * 32 + il;
+    const RowPos r = decode_row(p, q < 0 ? 0 : q);
+    unsigned v = 0;
+    int t = 0;
+    for (int ty = 0; ty < p.kh; ++ty)
+      for (int tx = 0; tx < 3; ++tx, ++t) {
+        const int sy = r.ybase + ty * p.tsign, sx = r.xbase + tx * p.tsign;
+        if (q >= 0 && r.ok && (unsigned)sy < (unsigned)r.SH && (unsigned)sx < (unsigned)r.SW) v |= 1u << t;
+      }
+    f_valid |= v << (16 * a);
+  }
+  int b_base[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int n = n0 + r0 + 64 * i;
+    b_base[i] = n < w_rows ? (n * w_ld8 + oct) * 16 : PP_BUF_OOB;
+  }
+  const int b_tap = w_rows * w_ld8 * 16;
+
+  float4 ra[TM][2];
+  uint4 rah[TM], ral[TM];
+  uint4 rbh[TN], rbl[TN];
+  int ty = g_begin / n_chunks, chunk = g_begin - ty * n_chunks;  // group being LOADED
+
+  auto load_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      int vo = s_base[i] + __mul24(ty, s_pitch[i] & ~15) + chunk * (BK * 4);
+      vo = ((s_pitch[i] >> ty) & 1) ? vo : PP_BUF_OOB;
+      const uint4 q0 = buf_load16(rs_a, vo, 0), q1 = buf_load16(rs_a, vo + 16, 0);
+      ra[i][0] = *reinterpret_cast<const float4*>(&q0);
+      ra[i][1] = *reinterpret_cast<const float4*>(&q1);
+    }
+  };
+  auto load_b = [&](int tx) {
+    const int b_uni = ((p.w_ty0 + ty) * p.w_kw + tx) * b_tap + chunk * (BK / 8 * 16);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      rbh[i] = buf_load16(rs_wh, b_base[i], b_uni);
+      rbl[i] = buf_load16(rs_wl, b_base[i], b_uni);
+    }
+  };
+  auto split_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) split8(ra[i][0], ra[i][1], &rah[i], &ral[i]);
+  };
+  auto store_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int slot = oct * BM + ((r0 + 64 * i + 2 * oct) & (BM - 1));
+      Ahi[slot] = rah[i];
+      Alo[slot] = ral[i];
+    }
+  };
+  auto store_b = [&]() {
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int slot = oct * BN + ((r0 + 64 * i + 2 * oct) & (BN - 1));
+      Bhi[slot] = rbh[i];
+      Blo[slot] = rbl[i];
+    }
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // multiply the tile in LDS as tap (c_ty, TX): fragments of the gathered operand at row offset dx, zeroed where the tap pads
+  auto mma_tile = [&](int c_ty, auto tx_c) {
+    constexpr int TX = decltype(tx_c)::value;
+    const int dx = p.off_x + TX * p.tsign;
+    const unsigned tap_bits = (1u << (c_ty * 3 + TX)) * 0x10001u;  // the tap's bit in both 16-bit halves
+    const unsigned okm = f_valid & tap_bits;
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      const int o = 2 * s + h;
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const int slot = o * BM + ((wm * 32 * TM + a * 32 + il + dx + 2 * o) & (BM - 1));
+        const bool ok = ((okm >> (16 * a)) & 0xffffu) != 0;
+        uint4 t = Ahi[slot];
+        t = ok ? t : make_uint4(0u, 0u, 0u, 0u);
+        ah[a] = *reinterpret_cast<bf16x8*>(&t);
+        t = Alo[slot];
+        t = ok ? t : make_uint4(0u, 0u, 0u, 0u);
+        al[a] = *reinterpret_cast<bf16x8*>(&t);
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int slot = o * BN + ((wn * 32 * TN + b * 32 + il + 2 * o) & (BN - 1));
+        uint4 t = Bhi[slot];
+        bh[b] = *reinterpret_cast<bf16x8*>(&t);
+        t = Blo[slot];
+        bl[b] = *reinterpret_cast<bf16x8*>(&t);
+      }
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+        }
+      if (s == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  std::integral_constant<int, 0> t0;
+  std::integral_constant<int, 1> t1;
+  std::integral_constant<int, 2> t2;
+  load_a();
+  load_b(0);
+  split_a();
+  store_a();
+  store_b();
+  __syncthreads();
+  for (int g = g_begin; g < g_end; ++g) {
+    const int c_ty = ty;
+    // tx = 0: the weight tile of tx = 1 is fetched under it
+    load_b(1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_tile(c_ty, t0);
+    __syncthreads();
+    store_b();
+    __syncthreads();
+    // tx = 1
+    load_b(2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_tile(c_ty, t1);
+    __syncthreads();
+    store_b();
+    __syncthreads();
+    // tx = 2: the next group's gathered rows and its first weight tile are fetched, converted and written
+    {
+      const bool more = g + 1 < g_end;  // past the end: rewind to group 0 (a harmless re-load)
+      chunk += 1;
+      const bool wc = chunk == n_chunks;
+      chunk = wc ? 0 : chunk;
+      ty += wc ? 1 : 0;
+      chunk = more ? chunk : 0;
+      ty = more ? ty : 0;
+    }
+    load_b(0);
+    load_a();
+    __builtin_amdgcn_sched_barrier(0);
+    mma_tile(c_ty, t2);
+    split_a();
+    __syncthreads();
+    store_b();
+    store_a();
+    __syncthreads();
+  }
+  // rows 0 and BM - 1 of the tile are halo: clear their accumulators' way out by making them out of range
+  if (splits > 1) {
+    float* slice = g_ws + (long long)split * p.M * p.ld_out;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 32 * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int m = m0 + row;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          const int co = n0 + wn * 32 * TN + b * 32 + il;
+          if (row >= 1 && row <= BM - 2 && m < p.M && co < ((p.Nout + 3) & ~3)) slice[(long long)m * p.ld_out + co] = acc[a][b][r];
+        }
+      }
+    return;
+  }
+  epilogue3<TM, TN, false, 4, false, true>(p, acc, smem, m0, n0, tid, wm, wn, il, h, g_bias, g_addend, g_mask, g_out, nullptr, nullptr);
+}
+
 // parity class without taps (e.g. the odd cells of a 1x1 stride-2 conv): dx = mask?(addend or 0) at the class rows
 __global__ void class_fill_kernel(const IgemmParams p, const float* __restrict__ g_addend, const float* __restrict__ g_mask,
                                   float* __restrict__ g_out) {
@@ -724,6 +961,20 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
     hipLaunchKernelGGL((igemm3f_kernel<TM, TN, false, false, true>), grid, dim3(256), 0, st, p, (const void*)p.src, nullptr, (unsigned)a_bytes, whi,
                        wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)nullptr, (uint2*)nullptr, w_rows, w_ld8, 1, nullptr);
     return;
+  }
+  if constexpr (TM <= 2) {
+    static const bool x_on = []() { const char* e = getenv("PP_CONV3_XREUSE"); return !(e && e[0] == '0'); }();
+    bool same = fast && x_on && !ahi && !ohi && !p.sc_on && p.kw == 3 && p.mul == 1 && p.div == 1 && p.src != nullptr &&
+                p.w_tstep == 1 && p.w_tx0 == 0;
+    for (int i = 0; i < p.n_seg && same; ++i)
+      same = p.seg[i].OH == p.seg[i].SH && p.seg[i].OW == p.seg[i].SW && p.seg[i].row_begin == p.seg[i].src_row_begin;
+    if (same) {
+      const int n_tiles_mx = (p.M + BM - 3) / (BM - 2);  // tiles overlap by two rows
+      const dim3 gridx((unsigned)(n_tiles_mx * p.n_tiles_n * splits));
+      hipLaunchKernelGGL((igemm3x_kernel<TM, TN>), gridx, dim3(256), 0, st, p, (const void*)p.src, (unsigned)a_bytes, whi, wlo, (unsigned)w_bytes,
+                         p.bias, p.addend, p.mask_src, p.out, w_rows, w_ld8, splits, ws);
+      return;
+    }
   }
   auto go = [&](auto ap, auto op) {
     constexpr bool AP = decltype(ap)::value, OP = decltype(op)::value;

@@ -273,14 +273,15 @@ def test_conv_bf16x3_fwd_bwd_data(ctx, case):
     want = torch.cat([torch.relu(r + q).reshape(-1, cout) for r, q in zip(ref, res)], dim=0).numpy()
     e = rel_err(y.cpu().numpy()[:, :cout], want)
     assert e < 1e-4, e
-    # same launch with the gathered operand pre-split into (hi, lo) planes: bit-identical result
+    # same conv with the gathered operand pre-split into (hi, lo) planes: same products; the launch may take a different
+    # kernel (tap order), so equal up to f32 summation order
     xh, xl = torch.zeros_like(x, dtype=torch.int16), torch.zeros_like(x, dtype=torch.int16)
     ops.split_planes3(ctx, x, xh, xl)
     assert rel_err((xh.view(torch.bfloat16).float() + xl.view(torch.bfloat16).float()).cpu().numpy(), x.cpu().numpy()) < 2e-5
     y2 = torch.full_like(y, float("nan"))
     yh, yl = torch.zeros_like(y, dtype=torch.int16), torch.zeros_like(y, dtype=torch.int16)
     ops.conv_fwd3(ctx, d, None, fh, fl, bd.cuda(), _cat_rows(res, ld_y), True, y2, x_planes=(xh, xl), y_planes=(yh, yl))
-    assert torch.equal(y2[:, :cout], y[:, :cout])
+    assert rel_err(y2[:, :cout].cpu().numpy(), y[:, :cout].cpu().numpy()) < 2e-6
     # ... and the epilogue's pre-split copy of the output is exactly what the split kernel makes of it
     wh, wl = torch.zeros_like(yh), torch.zeros_like(yl)
     ops.split_planes3(ctx, torch.nan_to_num(y2), wh, wl)
@@ -312,7 +313,7 @@ def test_conv_bf16x3_fwd_bwd_data(ctx, case):
     dx2 = torch.full_like(dx, float("nan"))
     xh2, xl2 = torch.zeros_like(dx, dtype=torch.int16), torch.zeros_like(dx, dtype=torch.int16)
     ops.conv_bwd_data3(ctx, d, None, dh, dl, _cat_rows(addend), _cat_rows(rsrc), dx2, dy_planes=(gh, gl), dx_planes=(xh2, xl2))
-    assert torch.equal(dx2, dx)
+    assert rel_err(dx2.cpu().numpy(), dx.cpu().numpy()) < 2e-6
     wh, wl = torch.zeros_like(xh2), torch.zeros_like(xl2)
     ops.split_planes3(ctx, dx2, wh, wl)
     assert torch.equal(xh2, wh) and torch.equal(xl2, wl)
