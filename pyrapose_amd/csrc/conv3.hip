@@ -564,11 +564,12 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3x_kernel(
     unsigned w_bytes, const float* __restrict__ g_bias, const float* __restrict__ g_addend, const float* __restrict__ g_mask,
     float* __restrict__ g_out, int w_rows, int w_ld8, int splits, float* __restrict__ g_ws) {
   constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, NO = BK / 8;
-  constexpr int SMEM_U4 = 2 * NO * (BM + BN);
+  constexpr int AP1 = NO * BM + 1;  // plane size: the tile + one all-zero slot that padded taps read instead of their row
+  constexpr int SMEM_U4 = 2 * AP1 + 2 * NO * BN;
   __shared__ __attribute__((aligned(16))) uint4 smem[SMEM_U4];
   uint4* Ahi = smem;
-  uint4* Alo = Ahi + NO * BM;
-  uint4* Bhi = Alo + NO * BM;
+  uint4* Alo = Ahi + AP1;
+  uint4* Bhi = Alo + AP1;
   uint4* Blo = Bhi + NO * BN;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -688,13 +689,13 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3x_kernel(
       bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
       for (int a = 0; a < TM; ++a) {
-        const int slot = o * BM + ((wm * 32 * TM + a * 32 + il + dx + 2 * o) & (BM - 1));
         const bool ok = ((okm >> (16 * a)) & 0xffffu) != 0;
+        // padded taps read the all-zero slot: one address select per fragment (zeroing the eight fragment registers
+        // instead measured 1 % slower)
+        const int slot = ok ? o * BM + ((wm * 32 * TM + a * 32 + il + dx + 2 * o) & (BM - 1)) : NO * BM;
         uint4 t = Ahi[slot];
-        t = ok ? t : make_uint4(0u, 0u, 0u, 0u);
         ah[a] = *reinterpret_cast<bf16x8*>(&t);
         t = Alo[slot];
-        t = ok ? t : make_uint4(0u, 0u, 0u, 0u);
         al[a] = *reinterpret_cast<bf16x8*>(&t);
       }
 #pragma unroll
@@ -720,6 +721,10 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3x_kernel(
   std::integral_constant<int, 0> t0;
   std::integral_constant<int, 1> t1;
   std::integral_constant<int, 2> t2;
+  if (threadIdx.x == 0) {
+    Ahi[NO * BM] = make_uint4(0u, 0u, 0u, 0u);
+    Alo[NO * BM] = make_uint4(0u, 0u, 0u, 0u);
+  }
   load_a();
   load_b(0);
   split_a();
