@@ -1820,8 +1820,17 @@ extern "C" int pp_conv2d_nhwc_bwd_weight_bf16x3(pp_ctx* ctx, const pp_conv_desc*
   fill_segs(ctx, d, true, p.seg, &p.M, &p.src_rows);
   p.Cin = d->cin; p.Cout = d->cout;
   p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
-  const bool big_k = (d->cin % 128 == 0);
-  const bool big_n = ((d->cout + 127) / 128 * 128) <= ((d->cout + 63) / 64 * 64);
+  // (tools/sweep_wgrad.sh: the small 1x1 layers of res4 / res5 take ~35 us for ANY tile / split choice: ~19 latency-bound
+  // steps of a lone workgroup per CU plus the f32 atomics of splits x |dW|.  Register double-buffering of the staged tiles
+  // (loads two steps ahead) shortens such lone-workgroup launches by 10-20 % in isolation, but no measurable step time.)
+  bool big_k = (d->cin % 128 == 0);
+  bool big_n = ((d->cout + 127) / 128 * 128) <= ((d->cout + 63) / 64 * 64);
+  if (const char* e = getenv("PP_WGRAD3_TILE")) {  // tuning hook: "1,1" / "1,2" / "2,1" / "2,2"
+    if (e[0] && e[1] == ',' && e[2]) {
+      big_k = big_k && e[0] == '2';
+      big_n = e[2] == '2';
+    }
+  }
   if (big_k && big_n) launch_wgrad3<2, 2>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias);
   else if (big_k) launch_wgrad3<2, 1>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias);
   else if (big_n) launch_wgrad3<1, 2>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias);
