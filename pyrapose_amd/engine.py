@@ -201,7 +201,6 @@ class Engine(object):
         # conv arithmetic: "bf16x3" (default) = 3 x bf16 MFMA per product, f32 accumulation (conv3.hip; ~2^-16 per
         # product, whole-graph outputs within 2e-5 of the f32 path) for every conv except the 3-channel stem;
         # "f32" = exact f32 MFMA everywhere (conv.hip).  Both hold the 1e-3 head-output bar.
-        import os as _os
         self.conv_mode = conv_mode or _os.environ.get("PP_CONV_MODE", "bf16x3")
         assert self.conv_mode in ("f32", "bf16x3"), self.conv_mode
         # PP_ACT_PLANES=1: conv epilogues also write their output pre-split into bf16 planes and the weight-gradient
@@ -216,7 +215,7 @@ class Engine(object):
         # workgroups of another -- see DESIGN.md §Concurrency.  PP_LANES=1 serialises everything on lane 0.
         # Measured (tools/phase_times.py, batch 8): forward 8.20 / 8.02 / 8.44 ms and backward 15.45 / 14.19 / 14.13 ms
         # at 1 / 2 / 3 lanes -> two lanes (a third concurrent head chain only adds cache pressure).
-        import os
+        os = _os
         self.n_lanes = max(1, min(3, int(os.environ.get("PP_LANES", "2"))))
         self.streams = [ctx.stream] + [torch.cuda.Stream(device=ctx.device) for _ in range(self.n_lanes - 1)]
         self.ctxs = [ctx] + [ops.Context(ctx.device, st) for st in self.streams[1:]]
