@@ -158,6 +158,16 @@ int pp_pack_rgb_to_4(pp_ctx* ctx, size_t n_pixels, const float* x3, float* x4);
  * padding and in channel 3.  sizes_hw is a HOST array of 2*n_img ints (n_img <= 64). */
 int pp_preprocess_caffe_u8(pp_ctx* ctx, int n_img, int H, int W, const int* sizes_hw_host, const unsigned char* images_u8,
                            float* x4);
+/* The same two producers writing into a zero frame [n_img][Hp][Wp][4] with the image at (pad, pad): the input layout of
+ * pp_stem7x7s2_fwd_bf16x3 (pad = 3). */
+int pp_pack_rgb_to_4_padded(pp_ctx* ctx, int n_img, int H, int W, int Hp, int Wp, int pad, const float* x3, float* x4p);
+int pp_preprocess_caffe_u8_padded(pp_ctx* ctx, int n_img, int H, int W, int Hp, int Wp, int pad, const int* sizes_hw_host,
+                                  const unsigned char* images_u8, float* x4p);
+/* keras_resnet conv1 (ZeroPadding2D(3) + Conv2D(64, 7, strides 2), models/resnet.py:87) + folded BN + ReLU on the bf16x3
+ * path: x4p as above (Hp >= H + 6, Wp >= W + 8, even), weight planes [7][cout][32] (kernel row ty, column tx * 4 + c),
+ * y [n_img * OH * OW][ld_y] with OH = (H - 1) / 2 + 1. */
+int pp_stem7x7s2_fwd_bf16x3(pp_ctx* ctx, int n_img, int H, int W, int Hp, int Wp, const float* x4p, const void* w_hi,
+                            const void* w_lo, int cout, const float* bias, int relu, float* y, int ld_y);
 
 /* ---- head output export ---------------------------------------------------------------
  * Head convs write level-major matrices [rows][ld]; Keras concatenates the per-level reshapes on

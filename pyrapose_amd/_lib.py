@@ -94,6 +94,9 @@ _SIGS = {
     "pp_add_n": (_i, [_p, _sz, _p, _p, _p, _p]),
     "pp_relu_fwd": (_i, [_p, C.c_size_t, _p, _p]),
     "pp_preprocess_caffe_u8": (_i, [_p, _i, _i, _i, C.POINTER(C.c_int), _p, _p]),
+    "pp_preprocess_caffe_u8_padded": (_i, [_p, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_int), _p, _p]),
+    "pp_pack_rgb_to_4_padded": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "pp_stem7x7s2_fwd_bf16x3": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _i]),
     "pp_pack_rgb_to_4": (_i, [_p, _sz, _p, _p]),
     "pp_export_head": (_i, [_p, C.POINTER(RowSpace), _i, _i, _p, _i, _i, _p]),
     "pp_count_positives": (_i, [_p, _sz, _p, _sz, _i, _p, _sz, _i, _p, _p]),

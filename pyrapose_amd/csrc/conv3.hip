@@ -1100,6 +1100,40 @@ extern "C" int pp_conv2d_nhwc_fwd_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, con
   return PP_OK;
 }
 
+// The 7x7 stride-2 RGB stem on the bf16 path.  Input: the packed 4-channel image inside a zero frame [n_img][Hp][Wp][4] with
+// the image at (3, 3) (pp_pack_rgb_to_4_padded / pp_preprocess_caffe_u8_padded), Hp >= H + 6, Wp >= W + 8, Wp even.  Each
+// kernel ROW (7 taps x 4 channels = 28 contiguous floats of the frame, padded to 32) is one tap of a 7x1 convolution over
+// 32 "channels" that overlap between neighbouring pixels -- the gather of igemm3f needs nothing else: base offset of pixel
+// (2 oy + ty, 2 ox), 32 consecutive floats.  Weights: planes [7][cout][32] with plane row ty, column tx * 4 + c (zeros for
+// c == 3 and tx == 7), see Engine._build_stem.  224 of the executed 7 x 32 reduction steps are 147 algorithmic.
+extern "C" int pp_stem7x7s2_fwd_bf16x3(pp_ctx* ctx, int n_img, int H, int W, int Hp, int Wp, const float* x4p, const void* w_hi,
+                                       const void* w_lo, int cout, const float* bias, int relu, float* y, int ld_y) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, x4p && w_hi && w_lo && y && pp_is_aligned16(x4p) && pp_is_aligned16(y) && pp_is_aligned16(w_hi) && pp_is_aligned16(w_lo),
+               PP_ERR_ARG, "pp_stem7x7s2_fwd_bf16x3: null / unaligned tensor");
+  PP_CHECK_ARG(ctx, n_img > 0 && H > 0 && W > 0 && Hp >= H + 6 && Wp >= W + 8 && Wp % 2 == 0 && cout > 0 && ld_y % 4 == 0 && ld_y >= ((cout + 3) & ~3),
+               PP_ERR_SHAPE, "pp_stem7x7s2_fwd_bf16x3: bad geometry");
+  const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.src = x4p; p.out = y; p.bias = bias;
+  p.ld_src = 4; p.ld_out = ld_y;
+  p.relu = relu;
+  p.n_seg = 1;
+  p.seg[0].row_begin = 0; p.seg[0].src_row_begin = 0;
+  p.seg[0].OH = OH; p.seg[0].OW = OW; p.seg[0].SH = Hp; p.seg[0].SW = Wp;
+  p.M = n_img * OH * OW;
+  p.src_rows = (long long)n_img * Hp * Wp;
+  p.Cred = 32; p.Nout = cout; p.w_tap_rows = 32;
+  p.kh = 7; p.kw = 1;
+  p.mul = 2; p.tsign = 1; p.off_y = 0; p.off_x = 0; p.div = 1;
+  p.w_ty0 = 0; p.w_tx0 = 0; p.w_tstep = 1; p.w_kw = 1; p.w_taps = 7;
+  PP_CHECK_ARG(ctx, igemm3_fast_ok(p, false, cout, 4), PP_ERR_SHAPE, "pp_stem7x7s2_fwd_bf16x3: frame too large for 31-bit offsets");
+  dispatch3(ctx, p, nullptr, nullptr, w_hi, w_lo, cout, 4, nullptr, nullptr);
+  PP_CHECK_LAUNCH(ctx, "pp_stem7x7s2_fwd_bf16x3");
+  return PP_OK;
+}
+
 extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* dy, const void* dy_hi, const void* dy_lo,
                                               const void* w_hi, const void* w_lo, const float* addend, int ld_add,
                                               const float* relu_src, int ld_rs, float* dx, void* dx_hi, void* dx_lo) {

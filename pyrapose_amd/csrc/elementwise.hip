@@ -175,6 +175,32 @@ __global__ void pack_rgb4_kernel(size_t n_pix, const float* __restrict__ x3, flo
     x4[i] = make_float4(x3[3 * i], x3[3 * i + 1], x3[3 * i + 2], 0.f);
 }
 
+// padded frame for the bf16x3 stem: output [n_img][Hp][Wp][4], image at (pad, pad), zeros elsewhere and in channel 3
+__global__ void pack_rgb4_padded_kernel(int n_img, int H, int W, int Hp, int Wp, int pad, const float* __restrict__ x3,
+                                        float4* __restrict__ x4) {
+  const size_t n_pix = (size_t)n_img * Hp * Wp;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_pix; i += (size_t)gridDim.x * blockDim.x) {
+    const int X = (int)(i % Wp), Y = (int)((i / Wp) % Hp), b = (int)(i / ((size_t)Wp * Hp));
+    const int x = X - pad, y = Y - pad;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
+      const float* s = x3 + (((size_t)b * H + y) * W + x) * 3;
+      v = make_float4(s[0], s[1], s[2], 0.f);
+    }
+    x4[i] = v;
+  }
+}
+
+extern "C" int pp_pack_rgb_to_4_padded(pp_ctx* ctx, int n_img, int H, int W, int Hp, int Wp, int pad, const float* x3, float* x4p) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, x3 && x4p && pp_is_aligned16(x4p), PP_ERR_ARG, "pp_pack_rgb_to_4_padded: null / unaligned tensor");
+  PP_CHECK_ARG(ctx, n_img > 0 && H > 0 && W > 0 && pad >= 0 && Hp >= H + pad && Wp >= W + pad, PP_ERR_SHAPE, "pp_pack_rgb_to_4_padded: bad frame");
+  hipLaunchKernelGGL(pack_rgb4_padded_kernel, dim3(grid_for((size_t)n_img * Hp * Wp, 256, ctx)), dim3(256), 0, ctx->stream, n_img, H, W, Hp, Wp,
+                     pad, x3, (float4*)x4p);
+  PP_CHECK_LAUNCH(ctx, "pp_pack_rgb_to_4_padded");
+  return PP_OK;
+}
+
 extern "C" int pp_pack_rgb_to_4(pp_ctx* ctx, size_t n_pixels, const float* x3, float* x4) {
   PP_REQUIRE_CTX(ctx);
   PP_CHECK_ARG(ctx, x3 && x4, PP_ERR_ARG, "pp_pack_rgb_to_4: null tensor");
@@ -189,22 +215,40 @@ extern "C" int pp_pack_rgb_to_4(pp_ctx* ctx, size_t n_pixels, const float* x3, f
 // preprocessing/generator.py:319-336 compute_inputs: images copied into the upper-left corner of a ZERO batch, i.e.
 // the padding stays 0.0 (it is not mean-subtracted).  sizes[b] = (h_b, w_b) of image b inside the [H, W] batch frame.
 struct U8Sizes { int hw[2 * 64]; };
-__global__ void preprocess_u8_kernel(int n_img, int H, int W, U8Sizes sz, const unsigned char* __restrict__ u8, float4* __restrict__ x4) {
-  const size_t n_pix = (size_t)n_img * H * W;
+__global__ void preprocess_u8_kernel(int n_img, int H, int W, int Hp, int Wp, int pad, U8Sizes sz, const unsigned char* __restrict__ u8,
+                                     float4* __restrict__ x4) {
+  const size_t n_pix = (size_t)n_img * Hp * Wp;  // output frame [Hp][Wp], image frame [H][W] at (pad, pad)
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_pix; i += (size_t)gridDim.x * blockDim.x) {
-    const int x = (int)(i % W), y = (int)((i / W) % H), b = (int)(i / ((size_t)W * H));
+    const int X = (int)(i % Wp), Y = (int)((i / Wp) % Hp), b = (int)(i / ((size_t)Wp * Hp));
+    const int x = X - pad, y = Y - pad;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (y < sz.hw[2 * b] && x < sz.hw[2 * b + 1]) {
-      v.x = (float)u8[3 * i] - 103.939f;
-      v.y = (float)u8[3 * i + 1] - 116.779f;
-      v.z = (float)u8[3 * i + 2] - 123.68f;
+    if (x >= 0 && y >= 0 && y < sz.hw[2 * b] && x < sz.hw[2 * b + 1]) {
+      const unsigned char* s = u8 + (((size_t)b * H + y) * W + x) * 3;
+      v.x = (float)s[0] - 103.939f;
+      v.y = (float)s[1] - 116.779f;
+      v.z = (float)s[2] - 123.68f;
     }
     x4[i] = v;
   }
 }
 
+static int preprocess_u8(pp_ctx* ctx, int n_img, int H, int W, int Hp, int Wp, int pad, const int* sizes_hw_host, const unsigned char* images_u8,
+                         float* x4);
+
 extern "C" int pp_preprocess_caffe_u8(pp_ctx* ctx, int n_img, int H, int W, const int* sizes_hw_host, const unsigned char* images_u8,
                                       float* x4) {
+  return preprocess_u8(ctx, n_img, H, W, H, W, 0, sizes_hw_host, images_u8, x4);
+}
+
+extern "C" int pp_preprocess_caffe_u8_padded(pp_ctx* ctx, int n_img, int H, int W, int Hp, int Wp, int pad, const int* sizes_hw_host,
+                                             const unsigned char* images_u8, float* x4p) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, pad >= 0 && Hp >= H + pad && Wp >= W + pad, PP_ERR_SHAPE, "pp_preprocess_caffe_u8_padded: bad frame");
+  return preprocess_u8(ctx, n_img, H, W, Hp, Wp, pad, sizes_hw_host, images_u8, x4p);
+}
+
+static int preprocess_u8(pp_ctx* ctx, int n_img, int H, int W, int Hp, int Wp, int pad, const int* sizes_hw_host, const unsigned char* images_u8,
+                         float* x4) {
   PP_REQUIRE_CTX(ctx);
   PP_CHECK_ARG(ctx, n_img > 0 && n_img <= 64 && H > 0 && W > 0, PP_ERR_SHAPE, "pp_preprocess_caffe_u8: 1..64 images per call");
   PP_CHECK_ARG(ctx, images_u8 && x4 && sizes_hw_host && pp_is_aligned16(x4), PP_ERR_ARG, "pp_preprocess_caffe_u8: null / unaligned tensor");
@@ -216,8 +260,8 @@ extern "C" int pp_preprocess_caffe_u8(pp_ctx* ctx, int n_img, int H, int W, cons
     sz.hw[2 * b] = sizes_hw_host[2 * b];
     sz.hw[2 * b + 1] = sizes_hw_host[2 * b + 1];
   }
-  hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid_for((size_t)n_img * H * W, 256, ctx)), dim3(256), 0, ctx->stream, n_img, H, W, sz,
-                     images_u8, (float4*)x4);
+  hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid_for((size_t)n_img * Hp * Wp, 256, ctx)), dim3(256), 0, ctx->stream, n_img, H, W, Hp, Wp,
+                     pad, sz, images_u8, (float4*)x4);
   PP_CHECK_LAUNCH(ctx, "pp_preprocess_caffe_u8");
   return PP_OK;
 }

@@ -356,9 +356,19 @@ class Engine(object):
         B, H, W = self.B, self.H, self.W
         ctx = self.ctx
         self.x_in = torch.zeros((B, H, W, 3), dtype=torch.float32, device="cuda")
-        x4 = self._new_act("input4", [(H, W)], 4)
-        self._push(Op(lambda: ops.pack_rgb_to_4(ctx, self.x_in, x4.t), "pointwise", "pack_rgb"), (), x4)
-        y = self._conv("conv1", x4, relu=True)
+        self.stem3 = self.conv_mode == "bf16x3" and _os.environ.get("PP_STEM3", "1") != "0"
+        if self.stem3:
+            # the stem on the bf16 path: the packed image sits at (3, 3) of a zero frame and every kernel ROW is one tap of
+            # a 7x1 conv over 32 overlapping "channels" (pp_stem7x7s2_fwd_bf16x3)
+            Hp, Wp = H + 6, (W + 8 + 1) // 2 * 2
+            self.stem_frame = (Hp, Wp)
+            x4 = self._new_act("input4", [(Hp, Wp)], 4)
+            self._push(Op(lambda: ops.pack_rgb_to_4_padded(ctx, self.x_in, x4.t, Hp, Wp), "pointwise", "pack_rgb"), (), x4)
+            y = self._build_stem3(x4)
+        else:
+            x4 = self._new_act("input4", [(H, W)], 4)
+            self._push(Op(lambda: ops.pack_rgb_to_4(ctx, self.x_in, x4.t), "pointwise", "pack_rgb"), (), x4)
+            y = self._conv("conv1", x4, relu=True)
         (h1, w1) = y.shapes[0]
         ph, pw = (h1 + 1) // 2, (w1 + 1) // 2
         pool = self._new_act("pool1", [(ph, pw)], 64)
@@ -416,6 +426,35 @@ class Engine(object):
         for a in self.acts.values():
             if a.pl is not None and not getattr(a, "conv3_consumers", 0) and a.pl[0]._base is None:  # (P4/P5 write slices of pyr's)
                 a.pl = None
+
+    def _build_stem3(self, x4):
+        B, H, W = self.B, self.H, self.W
+        Hp, Wp = self.stem_frame
+        s = self.params.specs["conv1"]
+        assert (s.k, s.stride, s.cin, int(s.pad)) == (7, 2, 3, 3)
+        oh, ow = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        y = self._new_act("conv1", [(oh, ow)], s.cout, _ru(s.cout, 32), False, True)
+        i16 = dict(dtype=torch.int16, device="cuda")
+        d = ops.make_conv_desc(B, [(Hp, Wp)], [(oh, ow)], 32, s.cout, 7, 2, 0, 0, 32, y.ld, _ru(s.cout, 16))
+        d.kw = 1  # 7 kernel rows x (7 taps x 4 channels -> 32)
+        self._stem = dict(desc=d, w=torch.zeros((7 * 32, _ru(s.cout, 16)), dtype=torch.float32, device="cuda"),
+                          hi=torch.zeros((7, s.cout, 32), **i16), lo=torch.zeros((7, s.cout, 32), **i16))
+        ctx = self.ctx
+        bias = self.params.view(self.params.w_eff, "conv1/bias")
+        st = self._stem
+        flops = 2.0 * y.rows * 49 * 3 * s.cout
+        self._push(Op(lambda: ops.stem7x7s2_fwd3(ctx, B, H, W, Hp, Wp, x4.t, st["hi"], st["lo"], s.cout, bias, True, y.t), "conv_fwd", "conv1",
+                      flops), (x4,), y)
+        return y
+
+    def _refresh_stem(self):
+        """conv1 (frozen) in the row-as-tap layout: plane row ty, column tx * 4 + c  <-  HWIO row (ty * 7 + tx) * 4 + c"""
+        st = self._stem
+        w = self.params.view(self.params.w_eff, "conv1/kernel")
+        st["w"].zero_()
+        for ty in range(7):
+            st["w"][ty * 32: ty * 32 + 28] = w[ty * 28: (ty + 1) * 28]
+        ops.conv_split_weights3(self.ctx, st["desc"], st["w"], st["hi"], st["lo"], None, None)
 
     def _pyramid_buffer(self, level_shapes):
         """P3 | P4 | ... rows in one buffer, so that the shared heads run as ONE multi-level launch"""
@@ -694,7 +733,10 @@ class Engine(object):
         if sizes_hw is None:
             sizes_hw = [(self.H, self.W)] * self.B
         x4 = self.acts["input4"]
-        ops.preprocess_caffe_u8(self.ctx, images_u8, sizes_hw, x4.t)
+        if self.stem3:
+            ops.preprocess_caffe_u8_padded(self.ctx, images_u8, sizes_hw, x4.t, *self.stem_frame)
+        else:
+            ops.preprocess_caffe_u8(self.ctx, images_u8, sizes_hw, x4.t)
         skip = self.fwd_ops[0]
         assert skip.name == "pack_rgb"
         fn, skip.fn = skip.fn, (lambda: None)
@@ -757,6 +799,8 @@ class Engine(object):
     def refresh_planes(self, only_trainable=False):
         """Re-split the effective weights into the bf16 (hi, lo) planes of the bf16x3 kernels (one launch)."""
         key = "_split_trainable" if only_trainable else "_split_all"
+        if not only_trainable and getattr(self, "stem3", False):
+            self._refresh_stem()
         batch = getattr(self, key, None)
         if batch is None:
             batch = ops.SplitWeightsBatch((pl["desc"], pl["w"], pl["fwd_hi"], pl["fwd_lo"], pl["dg_hi"], pl["dg_lo"])

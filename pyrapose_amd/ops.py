@@ -172,6 +172,24 @@ def preprocess_caffe_u8(ctx, images_u8, sizes_hw, x4):
     check(lib.pp_preprocess_caffe_u8(ctx.handle, Bn, H, W, arr, _ptr(images_u8), _ptr(x4)), ctx.handle, "pp_preprocess_caffe_u8")
 
 
+def pack_rgb_to_4_padded(ctx, x3, x4p, Hp, Wp, pad=3):
+    Bn, H, W, _ = x3.shape
+    check(lib.pp_pack_rgb_to_4_padded(ctx.handle, Bn, H, W, Hp, Wp, pad, _ptr(x3), _ptr(x4p)), ctx.handle, "pp_pack_rgb_to_4_padded")
+
+
+def preprocess_caffe_u8_padded(ctx, images_u8, sizes_hw, x4p, Hp, Wp, pad=3):
+    Bn, H, W, _ = images_u8.shape
+    assert images_u8.dtype == torch.uint8 and images_u8.is_contiguous()
+    arr = (C.c_int * (2 * Bn))(*[int(v) for hw in sizes_hw for v in hw])
+    check(lib.pp_preprocess_caffe_u8_padded(ctx.handle, Bn, H, W, Hp, Wp, pad, arr, _ptr(images_u8), _ptr(x4p)), ctx.handle,
+          "pp_preprocess_caffe_u8_padded")
+
+
+def stem7x7s2_fwd3(ctx, n_img, H, W, Hp, Wp, x4p, w_hi, w_lo, cout, bias, relu, y):
+    check(lib.pp_stem7x7s2_fwd_bf16x3(ctx.handle, n_img, H, W, Hp, Wp, _ptr(x4p), _ptr(w_hi), _ptr(w_lo), cout, _ptr(bias), int(bool(relu)),
+                                      _ptr(y), y.stride(0)), ctx.handle, "pp_stem7x7s2_fwd_bf16x3")
+
+
 def pack_rgb_to_4(ctx, x3, x4):
     check(lib.pp_pack_rgb_to_4(ctx.handle, x3.numel() // 3, _ptr(x3), _ptr(x4)), ctx.handle, "pp_pack_rgb_to_4")
 
