@@ -285,6 +285,8 @@ class Engine(object):
             waits = []
             for a in op.reads:
                 for p in a.prod_ops:
+                    if p is op:  # (an in-place companion launch, e.g. the plane split of a tensor, lists itself)
+                        continue
                     assert pos[id(p)] < i, "forward plan out of order: %s reads %s" % (op.name, a.name)
                     if p.lane != op.lane:
                         if p.done_ev is None:
@@ -356,7 +358,9 @@ class Engine(object):
         B, H, W = self.B, self.H, self.W
         ctx = self.ctx
         self.x_in = torch.zeros((B, H, W, 3), dtype=torch.float32, device="cuda")
-        self.stem3 = self.conv_mode == "bf16x3" and _os.environ.get("PP_STEM3", "1") != "0"
+        # (the row-as-tap stem needs the buffer-addressed loop: PP_CONV3_FAST=0 also turns it off)
+        self.stem3 = (self.conv_mode == "bf16x3" and _os.environ.get("PP_STEM3", "1") != "0" and
+                      _os.environ.get("PP_CONV3_FAST", "1") != "0")
         if self.stem3:
             # the stem on the bf16 path: the packed image sits at (3, 3) of a zero frame and every kernel ROW is one tap of
             # a 7x1 conv over 32 overlapping "channels" (pp_stem7x7s2_fwd_bf16x3)
