@@ -58,6 +58,12 @@ CASES = [
     ("bneck3x3_zp1_c64", 2, [(9, 11)], 64, 64, 3, 1, 1, None),
     ("bneck1x1_c64_c256", 3, [(10, 6)], 64, 256, 1, 1, 0, None),
     ("ragged_rows", 1, [(5, 7)], 128, 192, 3, 1, "same", None),
+    # tap-row reuse (igemm3x) edges: fewer rows than one tile; image boundaries every 25 rows inside overlapping tiles;
+    # rows wider than a tile (the +-1 neighbours of a row live in the next tile); many tiny levels
+    ("x_tiny", 1, [(3, 4)], 64, 64, 3, 1, "same", None),
+    ("x_many_images", 7, [(5, 5)], 64, 96, 3, 1, "same", None),
+    ("x_wide_rows", 1, [(3, 150)], 32, 64, 3, 1, "same", None),
+    ("x_five_levels", 2, [(9, 12), (5, 6), (3, 3), (2, 2), (1, 1)], 64, 128, 3, 1, "same", None),
 ]
 
 
