@@ -43,6 +43,9 @@ SHAPES = {
     "r5a1": (8, [(30, 40)], 1024, 2048, 1, 2, 0),   # res5a_branch1: 1x1 stride 2
     "r4a1": (8, [(60, 80)], 512, 1024, 1, 2, 0),
     "r4a2a": (8, [(60, 80)], 512, 256, 1, 2, 0),
+    # tail-quantisation probes: 48384 rows = 384 row tiles of 126 -> exactly 2 (cout 512) / 1 (cout 256) rounds of 768 workgroups
+    "reg2r": (8, [(72, 84)], 512, 512, 3, 1, 1),
+    "cls1r": (8, [(72, 84)], 256, 256, 3, 1, 1),
     "occ1": (2, [(64, 64)], 512, 512, 3, 1, 1),
     "occ8": (16, [(64, 64)], 512, 512, 3, 1, 1),
     "big2": (16, [(64, 64)], 512, 512, 3, 1, 1),   # 256x128 tiles: 256*4 = 1024 workgroups = 2 per CU x 2 rounds
