@@ -45,6 +45,12 @@ int pp_ctx_set_stream(pp_ctx* ctx, void* hip_stream);
  * finishing pass adds the slices in a fixed order and applies bias / residual / mask / ReLU (deterministic, no
  * atomics).  A launch uses S * rows * ld_out * 4 bytes.  One buffer per context (= per stream); NULL, 0 removes it. */
 int pp_ctx_set_workspace(pp_ctx* ctx, void* device_buffer, size_t bytes);
+/* One-shot: the NEXT pp_conv2d_nhwc_fwd_bf16x3 / pp_conv2d_nhwc_bwd_data_bf16x3 call on this context, which must be given
+ * its gathered operand (x / dy) as float32, also writes that operand's bf16 (hi, lo) split into these planes -- the
+ * output of pp_split_planes_bf16x3 on it ([rows][ld] geometry; columns past the channels the conv reads are left
+ * untouched).  The kernel has the converted values in registers anyway; the weight-gradient launch of the same layer
+ * (pp_conv2d_nhwc_bwd_weight_bf16x3 with all four planes) then skips its own conversion.  NULL, NULL cancels. */
+int pp_ctx_set_split_capture(pp_ctx* ctx, void* hi, void* lo);
 const char* pp_last_error_string(pp_ctx* ctx);
 const char* pp_version(void);
 /* number of compute units / name of the device the ctx is bound to (for bench metadata) */

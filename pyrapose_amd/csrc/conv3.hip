@@ -339,6 +339,12 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, int voff, 
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+__device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, const uint4& v, int voff) {
+  u32x4 q;
+  q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
+  __builtin_amdgcn_raw_buffer_store_b128(q, r, voff, 0, 0);  // out-of-range offsets are dropped
+}
+
 // Measured and NOT kept (tools/conv_bench.py --shape r3 = exactly three rounds of workgroups, 128x128 tile): a 64-deep k-step
 // (twice the MFMAs per barrier pair, 2 workgroups/CU) and register double-buffering of the staged tiles (loads issued two
 // steps ahead, 190 VGPRs, 2 workgroups/CU) both land on the same 340-355 TFLOP/s as this loop; dependent MFMAs on one
@@ -562,11 +568,16 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
 // 34 %, no bank conflicts; for 31 % of the cycles all three resident waves of a SIMD wait (barriers, LDS / global
 // latency).  Tried against that: a double-buffered weight tile (one barrier per tap instead of two, 48 KB of LDS): the
 // kernel alone gains 1 %, the training step loses 1 % (less room for the other lane's workgroups on the CU) -- not kept.
-template <int TM, int TN>
+// CAP: the bf16 (hi, lo) split of the gathered f32 operand is also written out ([rows][ld_src] planes, the geometry of
+// pp_split_planes_bf16x3): for the centre kernel row (dy = 0: the staged rows are the tile's own rows; the BM - 2 inner
+// rows of all tiles cover every row once) the workgroups store the registers they have just converted, the output-channel
+// tiles of one row tile taking turns over the channel chunks.  The weight-gradient launch of the same layer then reads both operands pre-split (pp_ctx_set_split_capture).
+template <int TM, int TN, bool CAP>
 __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3x_kernel(
     const IgemmParams p, const void* __restrict__ g_a, unsigned a_bytes, const void* __restrict__ g_whi, const void* __restrict__ g_wlo,
     unsigned w_bytes, const float* __restrict__ g_bias, const float* __restrict__ g_addend, const float* __restrict__ g_mask,
-    float* __restrict__ g_out, int w_rows, int w_ld8, int splits, float* __restrict__ g_ws) {
+    float* __restrict__ g_out, int w_rows, int w_ld8, int splits, float* __restrict__ g_ws, void* __restrict__ g_chi,
+    void* __restrict__ g_clo) {
   constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, NO = BK / 8;
   constexpr int AP1 = NO * BM + 1;  // plane size: the tile + one all-zero slot that padded taps read instead of their row
   constexpr int SMEM_U4 = 2 * AP1 + 2 * NO * BN;
@@ -664,6 +675,25 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3x_kernel(
       Alo[slot] = ral[i];
     }
   };
+  // CAP: (ty, chunk) is the group whose converted rows the registers hold; plane byte offset = f32 byte offset / 2
+  const int ty_c = -p.off_y * p.tsign;  // kernel row with dy = 0
+  auto capture = [&]() {
+    if constexpr (CAP) {
+      const __amdgpu_buffer_rsrc_t rs_ch = __builtin_amdgcn_make_buffer_rsrc(g_chi, 0, a_bytes >> 1, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_cl = __builtin_amdgcn_make_buffer_rsrc(g_clo, 0, a_bytes >> 1, 0x00020000);
+      if (ty == ty_c && chunk % p.n_tiles_n == tile_n) {  // uniform: the output-channel tiles of a row tile take turns
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int row = r0 + 64 * i;
+          const int vo = s_base[i] + __mul24(ty, s_pitch[i] & ~15) + chunk * (BK * 4);
+          const bool ok = ((s_pitch[i] >> ty) & 1) && row >= 1 && row <= BM - 2;
+          const int co = ok ? (vo >> 1) : PP_BUF_OOB;
+          buf_store16(rs_ch, rah[i], co);
+          buf_store16(rs_cl, ral[i], co);
+        }
+      }
+    }
+  };
   auto store_b = [&]() {
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
@@ -737,6 +767,9 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3x_kernel(
   __syncthreads();
   for (int g = g_begin; g < g_end; ++g) {
     const int c_ty = ty;
+    // (CAP) the converted rows of this group are still in registers: their stores go out ahead of the tap's loads and
+    // complete under its MFMAs (one vmcnt for loads and stores: issued later they would stall the next weight tile)
+    capture();
     // tx = 0: the weight tile of tx = 1 is fetched under it
     load_b(1);
     __builtin_amdgcn_sched_barrier(0);
@@ -956,9 +989,18 @@ static bool igemm3_fast_ok(const IgemmParams& p, bool planes, int w_rows, int w_
          (long long)max_sw * p.ld_src * 4 < (1ll << 23) && p.src_rows > 0;
 }
 
+static void split_capture_pass(hipStream_t st, const IgemmParams& p, void* chi, void* clo) {
+  const size_t n8 = (size_t)(p.src_rows * (long long)p.ld_src / 8);
+  size_t blocks = (n8 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n8, (const float4*)p.src, (uint4*)chi, (uint4*)clo);
+}
+
+// chi / clo (may be NULL): also write the bf16 split of the gathered f32 operand (pp_ctx_set_split_capture) -- inside the
+// tap-row-reuse kernel where that one runs, by a separate pass over the operand otherwise
 template <int TM, int TN>
 static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const void* alo, const void* whi, const void* wlo, int w_rows,
-                          int w_ld8, void* ohi, void* olo, int splits, float* ws) {
+                          int w_ld8, void* ohi, void* olo, int splits, float* ws, void* chi = nullptr, void* clo = nullptr) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   p.n_tiles_n = (p.Nout + BN - 1) / BN;
   const int n_tiles_m = (p.M + BM - 1) / BM;
@@ -980,11 +1022,16 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
     if (same) {
       const int n_tiles_mx = (p.M + BM - 3) / (BM - 2);  // tiles overlap by two rows
       const dim3 gridx((unsigned)(n_tiles_mx * p.n_tiles_n * splits));
-      hipLaunchKernelGGL((igemm3x_kernel<TM, TN>), gridx, dim3(256), 0, st, p, (const void*)p.src, (unsigned)a_bytes, whi, wlo, (unsigned)w_bytes,
-                         p.bias, p.addend, p.mask_src, p.out, w_rows, w_ld8, splits, ws);
+      if (chi)
+        hipLaunchKernelGGL((igemm3x_kernel<TM, TN, true>), gridx, dim3(256), 0, st, p, (const void*)p.src, (unsigned)a_bytes, whi, wlo,
+                           (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, w_rows, w_ld8, splits, ws, chi, clo);
+      else
+        hipLaunchKernelGGL((igemm3x_kernel<TM, TN, false>), gridx, dim3(256), 0, st, p, (const void*)p.src, (unsigned)a_bytes, whi, wlo,
+                           (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, w_rows, w_ld8, splits, ws, nullptr, nullptr);
       return;
     }
   }
+  if (chi) split_capture_pass(st, p, chi, clo);
   auto go = [&](auto ap, auto op) {
     constexpr bool AP = decltype(ap)::value, OP = decltype(op)::value;
     if (fast)
@@ -1049,18 +1096,18 @@ static void pick_tile3(const pp_ctx* ctx, int M, int Nout, int ld_out, int n_ste
 }
 
 static void dispatch3(pp_ctx* ctx, IgemmParams& p, const void* ahi, const void* alo, const void* whi, const void* wlo, int w_rows,
-                      int w_ld8, void* ohi, void* olo) {
+                      int w_ld8, void* ohi, void* olo, void* chi = nullptr, void* clo = nullptr) {
   int tm, tn, splits;
   const int n_steps = p.kh * p.kw * (p.Cred / 32);
   const bool may_split = ctx->ws != nullptr && !ohi && p.out != nullptr && !p.sc_on && igemm3_fast_ok(p, ahi != nullptr, w_rows, w_ld8);
   pick_tile3(ctx, p.M, p.Nout, p.ld_out, n_steps, may_split, &tm, &tn, &splits);
   if (getenv("PP_CONV_DEBUG")) fprintf(stderr, "igemm3 M %d N %d steps %d -> tile %dx%d splits %d\n", p.M, p.Nout, n_steps, 64 * tm, 64 * tn, splits);
   float* ws = splits > 1 ? ctx->ws : nullptr;
-  if (tm == 4) launch_igemm3<4, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws);
-  else if (tm == 2 && tn == 2) launch_igemm3<2, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws);
-  else if (tm == 1 && tn == 2) launch_igemm3<1, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws);
-  else if (tm == 2 && tn == 1) launch_igemm3<2, 1>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws);
-  else launch_igemm3<1, 1>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws);
+  if (tm == 4) launch_igemm3<4, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo);
+  else if (tm == 2 && tn == 2) launch_igemm3<2, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo);
+  else if (tm == 1 && tn == 2) launch_igemm3<1, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo);
+  else if (tm == 2 && tn == 1) launch_igemm3<2, 1>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo);
+  else launch_igemm3<1, 1>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo);
   if (splits > 1) {
     const long long total = (long long)p.M * ((p.Nout + 3) >> 2);
     long long blocks = (total + 255) / 256;
@@ -1075,8 +1122,11 @@ extern "C" int pp_conv2d_nhwc_fwd_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, con
                                          const void* w_hi, const void* w_lo, const float* bias, const float* residual, int ld_res,
                                          int relu, float* y, void* y_hi, void* y_lo) {
   PP_REQUIRE_CTX(ctx);
+  void *chi = ctx->cap_hi, *clo = ctx->cap_lo;  // one-shot (pp_ctx_set_split_capture)
+  ctx->cap_hi = ctx->cap_lo = nullptr;
   int rc = check_desc(ctx, d, "pp_conv2d_nhwc_fwd_bf16x3");
   if (rc) return rc;
+  PP_CHECK_ARG(ctx, !chi || (x && !x_hi), PP_ERR_ARG, "pp_conv2d_nhwc_fwd_bf16x3: split capture needs the f32 operand");
   PP_CHECK_ARG(ctx, (x || (x_hi && x_lo)) && w_hi && w_lo && (y || (y_hi && y_lo)), PP_ERR_ARG, "pp_conv2d_nhwc_fwd_bf16x3: null tensor");
   PP_CHECK_ARG(ctx, (x_hi == nullptr) == (x_lo == nullptr), PP_ERR_ARG, "pp_conv2d_nhwc_fwd_bf16x3: x_hi and x_lo go together");
   PP_CHECK_ARG(ctx, d->cin % 32 == 0 && d->ld_x % 8 == 0, PP_ERR_SHAPE, "pp_conv2d_nhwc_fwd_bf16x3: cin %d must be a multiple of 32, ld_x of 8", d->cin);
@@ -1099,7 +1149,7 @@ extern "C" int pp_conv2d_nhwc_fwd_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, con
   p.w_ty0 = 0; p.w_tx0 = 0; p.w_tstep = 1; p.w_kw = d->kw; p.w_taps = d->kh * d->kw;
   PP_CHECK_ARG(ctx, (y_hi == nullptr) == (y_lo == nullptr) && (!y_hi || (d->ld_y % 4 == 0 && pp_is_aligned16(y_hi) && pp_is_aligned16(y_lo))),
                PP_ERR_ARG, "pp_conv2d_nhwc_fwd_bf16x3: output planes");
-  dispatch3(ctx, p, x_hi, x_lo, w_hi, w_lo, d->cout, d->cin / 8, y_hi, y_lo);
+  dispatch3(ctx, p, x_hi, x_lo, w_hi, w_lo, d->cout, d->cin / 8, y_hi, y_lo, chi, clo);
   PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_fwd_bf16x3");
   return PP_OK;
 }
@@ -1142,8 +1192,11 @@ extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d
                                               const void* w_hi, const void* w_lo, const float* addend, int ld_add,
                                               const float* relu_src, int ld_rs, float* dx, void* dx_hi, void* dx_lo) {
   PP_REQUIRE_CTX(ctx);
+  void *chi = ctx->cap_hi, *clo = ctx->cap_lo;  // one-shot (pp_ctx_set_split_capture)
+  ctx->cap_hi = ctx->cap_lo = nullptr;
   int rc = check_desc(ctx, d, "pp_conv2d_nhwc_bwd_data_bf16x3");
   if (rc) return rc;
+  PP_CHECK_ARG(ctx, !chi || (dy && !dy_hi), PP_ERR_ARG, "pp_conv2d_nhwc_bwd_data_bf16x3: split capture needs the f32 operand");
   PP_CHECK_ARG(ctx, (dy || (dy_hi && dy_lo)) && w_hi && w_lo && (dx || (dx_hi && dx_lo)), PP_ERR_ARG, "pp_conv2d_nhwc_bwd_data_bf16x3: null tensor");
   PP_CHECK_ARG(ctx, (dy_hi == nullptr) == (dy_lo == nullptr) && d->ld_y % 8 == 0, PP_ERR_ARG, "pp_conv2d_nhwc_bwd_data_bf16x3: planes / ld_y");
   const int cred = (d->cout + 31) / 32 * 32;
@@ -1196,6 +1249,7 @@ extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d
       if (r.M > 0 && r.kh > 0 && !(igemm3_fast_ok(r, false, d->cin, cred / 8) && r.M < (1 << 24))) ok = false;
     }
     if (ok) {
+      if (chi) split_capture_pass(ctx->stream, p, chi, clo);
       for (int c = 0; c < 4; ++c) {
         if (cls[c].M <= 0) continue;
         if (cls[c].kh > 0) {
@@ -1212,7 +1266,7 @@ extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d
       return PP_OK;
     }
   }
-  dispatch3(ctx, p, dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8, dx_hi, dx_lo);
+  dispatch3(ctx, p, dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8, dx_hi, dx_lo, chi, clo);
   PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_data_bf16x3");
   return PP_OK;
 }

@@ -45,6 +45,15 @@ extern "C" int pp_ctx_set_workspace(pp_ctx* ctx, void* zeroed, size_t bytes) {
   return PP_OK;
 }
 
+extern "C" int pp_ctx_set_split_capture(pp_ctx* ctx, void* hi, void* lo) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, (hi == nullptr) == (lo == nullptr) && pp_is_aligned16(hi) && pp_is_aligned16(lo), PP_ERR_ARG,
+               "pp_ctx_set_split_capture: hi and lo go together, 16-byte aligned");
+  ctx->cap_hi = hi;
+  ctx->cap_lo = lo;
+  return PP_OK;
+}
+
 extern "C" const char* pp_last_error_string(pp_ctx* ctx) { return ctx ? ctx->err : "no context"; }
 
 extern "C" int pp_device_info(pp_ctx* ctx, int* n_cu, char* name, int name_len) {

@@ -15,6 +15,8 @@ struct pp_ctx {
   char err[512];
   float* ws;        // caller-provided scratch for split-K partial sums (slices)
   size_t ws_bytes;
+  void* cap_hi;     // one-shot: the next bf16x3 fwd / bwd-data launch also writes the split of its gathered operand here
+  void* cap_lo;
 };
 
 static inline int pp_fail(pp_ctx* ctx, int code, const char* fmt, ...) {

@@ -207,6 +207,14 @@ class Engine(object):
         # launches read both operands from planes (gradients that only convs read are then never stored in f32).
         # Measured on the bench workload: bwd-weight -0.8 ms, forward + bwd-data epilogues +0.6..1.0 ms -> off by default.
         self.use_act_planes = self.conv_mode == "bf16x3" and _os.environ.get("PP_ACT_PLANES", "0") == "1"
+        # split capture (PP_CAPTURE=1): the forward / bwd-data launch of a 3x3 stride-1 conv also stores the bf16 split of
+        # its gathered operand (it has just computed it), and the weight-gradient launch of the layer, enqueued after the
+        # layer's bwd-data launch, reads both operands pre-split.  Off by default: the weight-gradient kernel alone gains
+        # 11-15 % and the capture costs the 512-channel launches nothing, but the training step does not move (one lane:
+        # +0.6 %; two lanes: -1 % -- with both lanes busy the MFMA pipes, not the conversion VALU, are what is shared).
+        self.capture = (self.conv_mode == "bf16x3" and not self.use_act_planes and _os.environ.get("PP_CAPTURE", "0") == "1")
+        self.capture_min_cin = int(_os.environ.get("PP_CAPTURE_MIN_CIN", "64"))
+        self.capture_skip = tuple(t for t in _os.environ.get("PP_CAPTURE_SKIP", "").split(",") if t)
         self.planes = OrderedDict()  # spec name -> dict(desc, fwd_hi, fwd_lo, dg_hi, dg_lo)
         self.fwd_ops, self.graph_ops, self.bwd_ops = [], [], []
         # Launch lanes: lane 0 is the ctx stream; lanes 1-2 are side streams.  Independent kernel chains (the three
@@ -323,6 +331,7 @@ class Engine(object):
         rt = residual.t if residual is not None else None
         flops = 2.0 * y.rows * k * k * s.cin * s.cout
         pl = None
+        x_cap = None
         if self.conv_mode == "bf16x3" and s.cin % 32 == 0:
             pl = self.planes.get(spec_name)
             if pl is None:
@@ -342,13 +351,24 @@ class Engine(object):
             if self._wants_planes(s):
                 x.conv3_consumers = getattr(x, "conv3_consumers", 0) + 1
             y.producer = s
-            self._push(Op(lambda: ops.conv_fwd3(ctx, desc, x.t, fh, fl, b, rt, relu, y.t, x.pl, y.pl), "conv_fwd", spec_name,
+            cap = None
+            if self._wants_capture(s, x):
+                if getattr(x, "cap_pl", None) is None:  # the first eligible consumer of x fills the planes
+                    x.cap_pl = cap = _new_planes(x.rows, x.ld)
+                x_cap = x.cap_pl
+            self._push(Op(lambda: ops.conv_fwd3(ctx, desc, x.t, fh, fl, b, rt, relu, y.t, x.pl, y.pl, cap), "conv_fwd", spec_name,
                           flops, None, lane), (x, residual), y)
         else:
             self._push(Op(lambda: ops.conv_fwd(ctx, desc, x.t, w, b, rt, relu, y.t), "conv_fwd", spec_name, flops, None, lane),
                        (x, residual), y)
-        self.graph_ops.append(dict(kind="conv", spec=s, x=x, y=y, residual=residual, desc=desc, w=w, flops=flops, planes=pl))
+        self.graph_ops.append(dict(kind="conv", spec=s, x=x, y=y, residual=residual, desc=desc, w=w, flops=flops, planes=pl,
+                                   x_cap=x_cap))
         return y
+
+    def _wants_capture(self, s, x):
+        return (self.train and self.capture and s.trainable and x.needs_grad and s.k == 3 and s.stride == 1 and (s.pad == "same" or str(s.pad) == "1")
+                and s.cin % 64 == 0 and s.cout % 32 == 0 and s.cin >= self.capture_min_cin and x.ld % 8 == 0 and x.pl is None
+                and not any(s.name.startswith(t) for t in self.capture_skip))
 
     def _wants_planes(self, s):
         # worth it only where the weight-gradient launch is big and conversion-bound: the wide 3x3 convs (regression head)
@@ -614,9 +634,13 @@ class Engine(object):
                 if last and self.use_act_planes and prod is not None and self._wants_planes(prod):
                     opl = _new_planes(act.rows, act.ld)
                 out = None if (opl is not None and planes_only) else new()
-                self.bwd_ops.append(Op(lambda d=op["desc"], gy=gy, dh=pl["dg_hi"], dl=pl["dg_lo"], acc=acc, mask=mask, out=out, opl=opl:
-                                       ops.conv_bwd_data3(ctx, d, gy.t, dh, dl, acc, mask, out, gy.pl, opl), "conv_dgrad",
+                gcap = op.get("g_cap")
+                self.bwd_ops.append(Op(lambda d=op["desc"], gy=gy, dh=pl["dg_hi"], dl=pl["dg_lo"], acc=acc, mask=mask, out=out, opl=opl, gcap=gcap:
+                                       ops.conv_bwd_data3(ctx, d, gy.t, dh, dl, acc, mask, out, gy.pl, opl, gcap), "conv_dgrad",
                                        op["spec"].name, op["flops"]))
+                pw = op.pop("pending_wgrad", None)
+                if pw is not None:  # the layer's weight gradient reads the planes this launch has just written
+                    self.bwd_ops.append(pw)
             else:
                 out = new()
                 self.bwd_ops.append(Op(lambda d=op["desc"], gy=gy, w=op["w"], acc=acc, mask=mask, out=out:
@@ -665,13 +689,22 @@ class Engine(object):
                     wr = (ek["offset"], eb["offset"] + eb["count"])
                     wl = 1 % self.n_lanes
                     wctx = self.ctxs[wl]
-                    if self.conv_mode == "bf16x3" and s.cin % 64 == 0:
+                    pl_ = op.get("planes")
+                    if (op.get("x_cap") is not None and x.needs_grad and pl_ is not None and pl_["dg_hi"] is not None
+                            and g.pl is None and g.t.shape == (y.rows, y.ld) and g.t.is_contiguous()):
+                        gc = op["g_cap"] = _new_planes(y.rows, y.ld)
+                        fn = lambda d=op["desc"], x=x, g=g, dw=dw, db=db, wctx=wctx, xp=op["x_cap"], gp=gc: \
+                            ops.conv_bwd_weight3(wctx, d, x.t, g.t, dw, db, xp, gp)
+                        op["pending_wgrad"] = Op(fn, "conv_wgrad", s.name, op["flops"], wr, wl)  # enqueued after the layer's dgrad
+                        fn = None
+                    elif self.conv_mode == "bf16x3" and s.cin % 64 == 0:
                         both = x.pl is not None and g.pl is not None
                         fn = lambda d=op["desc"], x=x, g=g, dw=dw, db=db, wctx=wctx, xp=(x.pl if both else None), gp=(g.pl if both else None): \
                             ops.conv_bwd_weight3(wctx, d, x.t, g.t, dw, db, xp, gp)
                     else:
                         fn = lambda d=op["desc"], xt=x.t, g=g, dw=dw, db=db, wctx=wctx: ops.conv_bwd_weight(wctx, d, xt, g.t, dw, db)
-                    self.bwd_ops.append(Op(fn, "conv_wgrad", s.name, op["flops"], wr, wl))
+                    if fn is not None:
+                        self.bwd_ops.append(Op(fn, "conv_wgrad", s.name, op["flops"], wr, wl))
                 if x.needs_grad:
                     x.contribs.append(("dgrad", op, g))
                 r = op["residual"]
@@ -700,6 +733,8 @@ class Engine(object):
                 for part, n in zip(op["parts"], op["rows"]):
                     part.contribs.append(("tensor", g.rows(r0, r0 + n)))
                     r0 += n
+        left = [op["spec"].name for op in self.graph_ops if op.get("pending_wgrad") is not None]
+        assert not left, "weight gradients waiting for a bwd-data launch that never came: %s" % left
 
     # ------------------------------------------------------------------------------------ execution
     def _fork(self, lanes):

@@ -116,7 +116,14 @@ def split_planes3(ctx, src, hi, lo):
     check(lib.pp_split_planes_bf16x3(ctx.handle, src.numel(), _ptr(src), _ptr(hi), _ptr(lo)), ctx.handle, "pp_split_planes_bf16x3")
 
 
-def conv_fwd3(ctx, d, x, w_hi, w_lo, bias, residual, relu, y, x_planes=None, y_planes=None):
+def _set_capture(ctx, planes):
+    if planes is not None:
+        check(lib.pp_ctx_set_split_capture(ctx.handle, _ptr(planes[0]), _ptr(planes[1])), ctx.handle, "pp_ctx_set_split_capture")
+
+
+def conv_fwd3(ctx, d, x, w_hi, w_lo, bias, residual, relu, y, x_planes=None, y_planes=None, x_capture=None):
+    """x_capture = (hi, lo): the launch also writes the bf16 split of x (pp_ctx_set_split_capture)."""
+    _set_capture(ctx, x_capture)
     ld_res = residual.stride(0) if residual is not None else 0
     xh, xl = x_planes if x_planes is not None else (None, None)
     yh, yl = y_planes if y_planes is not None else (None, None)
@@ -125,7 +132,9 @@ def conv_fwd3(ctx, d, x, w_hi, w_lo, bias, residual, relu, y, x_planes=None, y_p
           "pp_conv2d_nhwc_fwd_bf16x3")
 
 
-def conv_bwd_data3(ctx, d, dy, w_hi, w_lo, addend, relu_src, dx, dy_planes=None, dx_planes=None):
+def conv_bwd_data3(ctx, d, dy, w_hi, w_lo, addend, relu_src, dx, dy_planes=None, dx_planes=None, dy_capture=None):
+    """dy_capture = (hi, lo): the launch also writes the bf16 split of dy (pp_ctx_set_split_capture)."""
+    _set_capture(ctx, dy_capture)
     ld_add = addend.stride(0) if addend is not None else 0
     ld_rs = relu_src.stride(0) if relu_src is not None else 0
     dh, dl = dy_planes if dy_planes is not None else (None, None)

@@ -288,6 +288,16 @@ def test_conv_bf16x3_fwd_bwd_data(ctx, case):
     yh, yl = torch.zeros_like(y, dtype=torch.int16), torch.zeros_like(y, dtype=torch.int16)
     ops.conv_fwd3(ctx, d, None, fh, fl, bd.cuda(), _cat_rows(res, ld_y), True, y2, x_planes=(xh, xl), y_planes=(yh, yl))
     assert rel_err(y2[:, :cout].cpu().numpy(), y[:, :cout].cpu().numpy()) < 2e-6
+    # split capture: the launch also emits the bf16 split of its f32 operand (from the loop's registers where the tap-row
+    # reuse kernel runs, by a separate pass elsewhere); the result itself does not change
+    ch, cl = torch.full_like(xh, 0x7fc0), torch.full_like(xl, 0x7fc0)
+    y3 = torch.full_like(y, float("nan"))
+    ops.conv_fwd3(ctx, d, x, fh, fl, bd.cuda(), _cat_rows(res, ld_y), True, y3, x_capture=(ch, cl))
+    assert torch.equal(torch.nan_to_num(y3), torch.nan_to_num(y))
+    assert torch.equal(ch, xh) and torch.equal(cl, xl)
+    y3.fill_(float("nan"))
+    ops.conv_fwd3(ctx, d, x, fh, fl, bd.cuda(), _cat_rows(res, ld_y), True, y3)  # the capture is one-shot
+    assert torch.equal(torch.nan_to_num(y3), torch.nan_to_num(y))
     # ... and the epilogue's pre-split copy of the output is exactly what the split kernel makes of it
     wh, wl = torch.zeros_like(yh), torch.zeros_like(yl)
     ops.split_planes3(ctx, torch.nan_to_num(y2), wh, wl)
@@ -316,6 +326,12 @@ def test_conv_bf16x3_fwd_bwd_data(ctx, case):
     assert e < 1e-4, e
     gh, gl = torch.zeros_like(gy, dtype=torch.int16), torch.zeros_like(gy, dtype=torch.int16)
     ops.split_planes3(ctx, gy, gh, gl)
+    cred = (cout + 31) // 32 * 32
+    ch, cl = torch.full_like(gh, 0x7fc0), torch.full_like(gl, 0x7fc0)
+    dx3 = torch.full_like(dx, float("nan"))
+    ops.conv_bwd_data3(ctx, d, gy, dh, dl, _cat_rows(addend), _cat_rows(rsrc), dx3, dy_capture=(ch, cl))
+    assert torch.equal(dx3, dx)
+    assert torch.equal(ch[:, :cred], gh[:, :cred]) and torch.equal(cl[:, :cred], gl[:, :cred])
     dx2 = torch.full_like(dx, float("nan"))
     xh2, xl2 = torch.zeros_like(dx, dtype=torch.int16), torch.zeros_like(dx, dtype=torch.int16)
     ops.conv_bwd_data3(ctx, d, None, dh, dl, _cat_rows(addend), _cat_rows(rsrc), dx2, dy_planes=(gh, gl), dx_planes=(xh2, xl2))
@@ -443,6 +459,13 @@ def test_conv_bf16x3_split_k(ctx, splits, monkeypatch):
         y2, dx2 = run()
         y3, dx3 = run()
         assert torch.equal(y2, y3) and torch.equal(dx2, dx3)
+        # split capture under split-K: every (kernel row, channel chunk) group belongs to exactly one split
+        xh, xl = torch.zeros_like(x, dtype=torch.int16), torch.zeros_like(x, dtype=torch.int16)
+        ops.split_planes3(ctx, x, xh, xl)
+        ch, cl = torch.full_like(xh, 0x7fc0), torch.full_like(xl, 0x7fc0)
+        y4 = torch.full((rows, ld_y), float("nan"), dtype=torch.float32, device="cuda")
+        ops.conv_fwd3(ctx, d, x, fh, fl, bias, res, True, y4, x_capture=(ch, cl))
+        assert torch.equal(y4[:, :cout], y2) and torch.equal(ch, xh) and torch.equal(cl, xl)
     finally:
         ctx.set_workspace(0)
     assert rel_err(y2.cpu().numpy(), y1.cpu().numpy()) < 2e-6

@@ -151,6 +151,39 @@ def test_train_step_small_vs_oracle_f64(ctx, mode):
     print("worst relative gradient error", worst, "relative L2", np.sqrt(num / den))
 
 
+def test_split_capture_training_step_matches_default(ctx, monkeypatch):
+    """PP_CAPTURE=1: forward / bwd-data launches emit the bf16 split of their operands and the weight gradients (enqueued
+    after the layer's bwd-data launch) read planes.  Same products in the same order: outputs identical, gradients equal
+    up to the f32 atomics of the split weight-gradient launches."""
+    from pyrapose_amd import arch
+    from pyrapose_amd.engine import Engine
+    B, H, W, C = 2, 64, 96, 13
+    rng = np.random.default_rng(14)
+    Wt = arch.init_weights(C, seed=15)
+    x = torch.from_numpy(synth_input(rng, B, H, W)).cuda()
+    got = {}
+    for cap in ("0", "1"):
+        monkeypatch.setenv("PP_CAPTURE", cap)
+        eng = Engine(ctx, C, B, H, W, weights=Wt, train=True, conv_mode="bf16x3")
+        assert eng.capture == (cap == "1")
+        if cap == "0":
+            tg = [torch.from_numpy(a).cuda() for a in random_targets(rng, B, eng.N, eng.M3, C)]
+        eng.set_targets(*tg)
+        eng.forward(x)
+        eng.loss_and_backward()
+        torch.cuda.synchronize()
+        got[cap] = (eng.reg_out.t[:, :eng.reg_out.C].clone(), eng.cls_out.t[:, :eng.cls_out.C].clone(), eng.params.grad.clone(),
+                    [o.name for o in eng.bwd_ops if o.kind == "conv_wgrad"],
+                    [o["spec"].name for o in eng.graph_ops if o.get("g_cap") is not None])
+    print("captured layers:", got["1"][4])
+    assert len(got["1"][4]) >= 25 and not got["0"][4]  # head trunks, FPN 3x3 and the bottleneck 3x3 convs of res3..res5
+    assert sorted(got["0"][3]) == sorted(got["1"][3])
+    assert torch.equal(got["0"][0], got["1"][0]) and torch.equal(got["0"][1], got["1"][1])
+    g0, g1 = got["0"][2].double(), got["1"][2].double()
+    assert float((g0 - g1).norm() / g0.norm()) < 1e-6
+    assert float((g0 - g1).abs().max() / g0.abs().max()) < 1e-5
+
+
 def test_adam_clipnorm_kernel_vs_oracle(ctx):
     """Multi-tensor Adam + global-norm clip on synthetic tensors, three steps, both clip branches."""
     from pyrapose_amd import ops

@@ -95,6 +95,8 @@ def main():
         dxh, dxl = torch.zeros((rows_in, cin), **i16), torch.zeros((rows_in, cin), **i16)
         fns = {"fwd3pp": lambda: ops.conv_fwd3(ctx, d, None, fh, fl, bias, None, True, y, x_planes=(xh, xl), y_planes=(yh, yl)),
                "dgrad3pp": lambda: ops.conv_bwd_data3(ctx, d, None, dh, dl, None, x, dx, dy_planes=(gh, gl), dx_planes=(dxh, dxl)),
+               "fwd3c": lambda: ops.conv_fwd3(ctx, d, x, fh, fl, bias, None, True, y, x_capture=(xh, xl)),
+               "dgrad3c": lambda: ops.conv_bwd_data3(ctx, d, dy, dh, dl, None, x, dx, dy_capture=(gh, gl)),
                "fwd3p": lambda: ops.conv_fwd3(ctx, d, None, fh, fl, bias, None, True, y, x_planes=(xh, xl)),
                "dgrad3p": lambda: ops.conv_bwd_data3(ctx, d, None, dh, dl, None, x, dx, dy_planes=(gh, gl)),
                "wgrad3p": lambda: ops.conv_bwd_weight3(ctx, d, None, None, dw, db, x_planes=(xh, xl), dy_planes=(gh, gl)),
