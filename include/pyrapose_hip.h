@@ -290,6 +290,24 @@ int pp_pose_add_f64(pp_ctx* ctx, int n_pose, int n_pts, const double* pts, const
 int pp_pose_adi_f64(pp_ctx* ctx, int n_pose, int n_pts, const double* pts, const double* R_est, const double* t_est,
                     const double* R_gt, const double* t_gt, void* workspace, double* out);
 
+/* ---- RANSAC-PnP of the evaluation tail ----------------------------------------------------------------
+ * In place of cv2.solvePnPRansac(obj_points, est_points, K, None, iterationsCount=300, reprojectionError=5.0,
+ * confidence=0.99, flags=cv2.SOLVEPNP_ITERATIVE) + cv2.Rodrigues at utils/linemod_eval.py:479-485 (same call in the
+ * other *_eval.py): n_problems independent problems (one per detected class and image) in one launch; problem p owns
+ * the correspondences offsets[p] .. offsets[p+1] (device int array) of obj [N,3] / img [N,2] (float64, pixels) and the
+ * intrinsics K4[p] = (fx, fy, cx, cy).  points_per_vote = 8 for the reference's layout (k votes x the 8 cuboid corners,
+ * linemod_eval.py:421-431): a hypothesis then takes six distinct corners, each from a random vote; 0 = unstructured.
+ * Out: R [P,3,3] row-major (what cv2.Rodrigues(rvec) returns), t [P,3], n_inliers [P], inlier_mask [N] (1 = squared
+ * reprojection error < reproj_error^2), ok [P] (0: fewer than 4 inliers / no valid sample; R = I, t = 0 then).
+ * Deterministic for a given seed (counter-based draws, fixed-order reductions).  OpenCV is not in the reference tree:
+ * the estimator is this library's own (csrc/pnp.hip, restated in oracle/pnp_np.py) -- parity with cv2 is unpinned.
+ * workspace >= pp_pnp_ransac_workspace_bytes.  All iterations are run (no confidence-based early exit). */
+size_t pp_pnp_ransac_workspace_bytes(int n_problems, int iterations);
+int pp_pnp_ransac_f64(pp_ctx* ctx, int n_problems, const int* offsets_dev, int n_points_total, const double* obj,
+                      const double* img, const double* K4, int iterations, double reproj_error, unsigned long long seed,
+                      int points_per_vote, void* workspace, double* R_out, double* t_out, int* n_inliers,
+                      unsigned char* inlier_mask, int* ok);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,6 +124,8 @@ _SIGS = {
     "pp_pose_add_f64": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "pp_pose_adi_f64": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "pp_filter_detections_batch": (_i, [_p, _i, _i, _i, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p]),
+    "pp_pnp_ransac_workspace_bytes": (_sz, [_i, _i]),
+    "pp_pnp_ransac_f64": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _d, C.c_ulonglong, _i, _p, _p, _p, _p, _p, _p]),
 }
 
 EXPORTS = sorted(_SIGS)

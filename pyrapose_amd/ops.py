@@ -384,3 +384,24 @@ def pose_errors(ctx, pts, R_est, t_est, R_gt, t_gt, symmetric=False):
     fn = lib.pp_pose_adi_f64 if symmetric else lib.pp_pose_add_f64
     check(fn(ctx.handle, n, n_pts, *[_ptr(t) for t in args], _ptr(ws), _ptr(out)), ctx.handle, "pp_pose_adi_f64" if symmetric else "pp_pose_add_f64")
     return out
+
+
+def pnp_ransac(ctx, offsets, obj, img, K4, iterations=300, reproj_error=5.0, seed=0, points_per_vote=8):
+    """Batched RANSAC-PnP (pp_pnp_ransac_f64): cuda tensors offsets int32 [P+1], obj float64 [N,3], img float64 [N,2],
+    K4 float64 [P,4] -> (R [P,3,3], t [P,3], n_inliers int32 [P], inlier mask uint8 [N], ok int32 [P])."""
+    P = int(offsets.numel()) - 1
+    N = int(obj.shape[0])
+    assert offsets.dtype == torch.int32 and obj.dtype == torch.float64 and img.dtype == torch.float64 and K4.dtype == torch.float64
+    assert obj.shape == (N, 3) and img.shape == (N, 2) and K4.shape == (P, 4)
+    obj, img, K4, offsets = obj.contiguous(), img.contiguous(), K4.contiguous(), offsets.contiguous()
+    dev = obj.device
+    ws = torch.empty((max(1, lib.pp_pnp_ransac_workspace_bytes(P, int(iterations))),), dtype=torch.uint8, device=dev)
+    R = torch.empty((P, 3, 3), dtype=torch.float64, device=dev)
+    t = torch.empty((P, 3), dtype=torch.float64, device=dev)
+    n_in = torch.zeros((P,), dtype=torch.int32, device=dev)
+    mask = torch.zeros((max(N, 1),), dtype=torch.uint8, device=dev)
+    ok = torch.zeros((P,), dtype=torch.int32, device=dev)
+    check(lib.pp_pnp_ransac_f64(ctx.handle, P, _ptr(offsets), N, _ptr(obj), _ptr(img), _ptr(K4), int(iterations), float(reproj_error),
+                                int(seed) & 0xFFFFFFFFFFFFFFFF, int(points_per_vote), _ptr(ws), _ptr(R), _ptr(t), _ptr(n_in), _ptr(mask),
+                                _ptr(ok)), ctx.handle, "pp_pnp_ransac_f64")
+    return R, t, n_in, mask[:N], ok

@@ -1,0 +1,86 @@
+"""GPU: RANSAC-PnP kernel (pp_pnp_ransac_f64 through the C ABI) against its CPU restatement (oracle/pnp_np.py): same
+draws, same hypotheses, same winner, refined pose equal to ~1e-9; batched problems, failure cases, and the mirror of the
+cv2.solvePnPRansac call of utils/linemod_eval.py:479-485 feeding the ADD kernel (the decision of :530)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.test_oracle_pnp import BOX, K4, make_votes, rot_err_deg  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from pyrapose_amd.runtime import default_context
+    return default_context()
+
+
+def test_batch_matches_oracle(ctx):
+    from oracle import pnp_np as P
+    from pyrapose_amd.utils import pnp
+    rng = np.random.default_rng(5)
+    Kmat = np.array([[K4[0], 0, K4[2]], [0, K4[1], K4[3]], [0, 0, 1.0]])
+    probs, truth = [], []
+    for k, noise, out in ((12, 1.0, 0.25), (40, 1.5, 0.3), (3, 0.5, 0.0), (25, 2.0, 0.5)):
+        R, t, obj, img, clean = make_votes(rng, k, noise, out)
+        probs.append((obj, img, Kmat)); truth.append((R, t, clean))
+    got = pnp.solve_pnp_batch(probs, iterations=120, reproj_error=5.0, seed=9, points_per_vote=8, ctx=ctx)
+    for p, ((obj, img, _), (ok, Rg, tg, inl)) in enumerate(zip(probs, got)):
+        ok_o, Ro, to, mask_o = P.solve_pnp_ransac(obj, img, K4, iterations=120, reproj_error=5.0, seed=9, problem=p, points_per_vote=8)
+        assert ok == ok_o and ok
+        assert np.abs(Rg - Ro).max() < 1e-8 and np.abs(tg - to).max() < 1e-6, (p, np.abs(Rg - Ro).max(), np.abs(tg - to).max())
+        assert np.array_equal(inl, np.nonzero(mask_o)[0])
+        R, t, clean = truth[p]
+        assert rot_err_deg(Rg, R) < 3.0
+
+
+def test_deterministic_and_seed_dependent(ctx):
+    from pyrapose_amd.utils import pnp
+    rng = np.random.default_rng(6)
+    Kmat = np.array([[K4[0], 0, K4[2]], [0, K4[1], K4[3]], [0, 0, 1.0]])
+    R, t, obj, img, clean = make_votes(rng, 200, 1.5, 0.4)  # 1600 correspondences
+    a = pnp.solve_pnp_batch([(obj, img, Kmat)] * 3, iterations=300, seed=1, ctx=ctx)
+    b = pnp.solve_pnp_batch([(obj, img, Kmat)] * 3, iterations=300, seed=1, ctx=ctx)
+    for (ok1, R1, t1, i1), (ok2, R2, t2, i2) in zip(a, b):
+        assert ok1 and ok2 and np.array_equal(R1, R2) and np.array_equal(t1, t2) and np.array_equal(i1, i2)
+    # the three problems hold the same data but draw different samples: same optimum after refinement, to rounding
+    assert np.abs(a[0][1] - a[1][1]).max() < 1e-6 and np.abs(a[0][2] - a[2][2]).max() < 1e-4
+    assert rot_err_deg(a[0][1], R) < 0.5 and abs(a[0][2][2] - t[2]) < 0.01 * t[2]
+    assert len(a[0][3]) >= 0.97 * clean.sum()
+
+
+def test_cv2_call_mirror_and_add_decision(ctx):
+    from pyrapose_amd.utils import pnp, pose_error
+    rng = np.random.default_rng(7)
+    R, t, obj, img, clean = make_votes(rng, 30, 1.0, 0.2)
+    K = np.float32([K4[0], 0., K4[2], 0., K4[1], K4[3], 0., 0., 1.]).reshape(3, 3)
+    # the shapes of linemod_eval.py:427-430: float32 [8k,1,3] / [8k,1,2]
+    retval, rvec, tvec, inliers = pnp.solve_pnp_ransac(objectPoints=obj.astype(np.float32).reshape(-1, 1, 3),
+                                                       imagePoints=img.astype(np.float32).reshape(-1, 1, 2), cameraMatrix=K,
+                                                       distCoeffs=None, rvec=None, tvec=None, useExtrinsicGuess=False,
+                                                       iterationsCount=300, reprojectionError=5.0, confidence=0.99)
+    assert retval and rvec.shape == (3, 1) and tvec.shape == (3, 1) and inliers.dtype == np.int32 and inliers.shape[1] == 1
+    R_est = pnp.rodrigues(rvec)
+    assert np.allclose(pnp.rotation_vector(R_est), rvec, atol=1e-9)
+    assert rot_err_deg(R_est, R) < 1.5
+    model = rng.uniform(-1, 1, size=(500, 3)) * np.array([40.0, 30.0, 55.0])
+    err = pose_error.add(R_est, tvec, R, t.reshape(3, 1), model)
+    assert err < 0.1 * np.linalg.norm(BOX.max(0) - BOX.min(0))
+    with pytest.raises(ValueError):
+        pnp.solve_pnp_ransac(obj, img, K, distCoeffs=np.ones(5))
+
+
+def test_failure_cases(ctx):
+    from pyrapose_amd import ops
+    from pyrapose_amd.utils import pnp
+    Kmat = np.array([[K4[0], 0, K4[2]], [0, K4[1], K4[3]], [0, 0, 1.0]])
+    got = pnp.solve_pnp_batch([(BOX[:5], np.zeros((5, 2)), Kmat), (BOX, np.random.default_rng(0).uniform(0, 600, (8, 2)), Kmat)],
+                              iterations=50, points_per_vote=0, ctx=ctx)
+    assert not got[0][0] and np.array_equal(got[0][1], np.eye(3)) and len(got[0][3]) == 0
+    assert len(got[1][3]) < 8  # random pixels: whatever comes out, not all eight points fit
+    assert pnp.solve_pnp_batch([], ctx=ctx) == []
+    with pytest.raises(ValueError):
+        ops.pnp_ransac(ctx, torch.zeros(2, dtype=torch.int32, device="cuda"), torch.zeros((0, 3), dtype=torch.float64, device="cuda"),
+                       torch.zeros((0, 2), dtype=torch.float64, device="cuda"), torch.ones((1, 4), dtype=torch.float64, device="cuda"),
+                       iterations=0)
