@@ -84,3 +84,36 @@ def test_failure_cases(ctx):
         ops.pnp_ransac(ctx, torch.zeros(2, dtype=torch.int32, device="cuda"), torch.zeros((0, 3), dtype=torch.float64, device="cuda"),
                        torch.zeros((0, 2), dtype=torch.float64, device="cuda"), torch.ones((1, 4), dtype=torch.float64, device="cuda"),
                        iterations=0)
+
+
+def test_poses_from_prediction_outputs(ctx):
+    """The per-image / per-class block of linemod_eval.py:303-333 + 421-431 + 479-485 on synthetic prediction outputs."""
+    from pyrapose_amd.utils import pose_decode
+    from tests.test_oracle_pnp import project
+    from oracle import pnp_np as P
+    rng = np.random.default_rng(8)
+    B, N, C = 2, 3000, 3
+    boxes3D = rng.uniform(0, 600, size=(B, N, 16)).astype(np.float32)
+    scores = rng.uniform(0.0, 0.3, size=(B, N, C)).astype(np.float32)
+    corners = np.stack([BOX, BOX * 0.7, BOX * np.array([1.2, 0.8, 1.0])])
+    truth = {}
+    for (b, c, k) in ((0, 0, 60), (0, 2, 25), (1, 1, 40), (1, 2, 6)):  # the last one stays below min_votes
+        R = P.so3_exp(rng.normal(size=3)); t = np.array([rng.uniform(-100, 100), rng.uniform(-80, 80), rng.uniform(600, 1000)])
+        anchors = np.sort(rng.choice(N, size=k, replace=False))
+        uv = project(R, t, corners[c])
+        v = uv[None] + rng.normal(scale=1.0, size=(k, 8, 2))
+        bad = rng.uniform(size=k) < 0.2
+        v[bad] += rng.normal(scale=30.0, size=(int(bad.sum()), 8, 2))
+        boxes3D[b, anchors] = v.reshape(k, 16).astype(np.float32)
+        scores[b, anchors, c] = rng.uniform(0.55, 0.99, size=k).astype(np.float32)
+        truth[(b, c)] = (R, t, anchors)
+    Kmat = np.array([[K4[0], 0, K4[2]], [0, K4[1], K4[3]], [0, 0, 1.0]])
+    out = pose_decode.poses_from_outputs(boxes3D, scores, corners, Kmat, threshold=0.5, min_votes=10, seed=3, ctx=ctx)
+    assert [(o["image"], o["cls"]) for o in out] == [(0, 0), (0, 2), (1, 1)]
+    for o in out:
+        R, t, anchors = truth[(o["image"], o["cls"])]
+        assert np.array_equal(o["votes"], anchors)  # == np.where(scores[b, :, c] > 0.5)[0]
+        assert o["ok"] and rot_err_deg(o["R"], R) < 1.5 and abs(o["t"][2] - t[2]) < 0.02 * t[2]
+    assert pose_decode.poses_from_outputs(boxes3D, scores, corners, Kmat, threshold=0.995, ctx=ctx) == []
+    one = pose_decode.poses_from_outputs(boxes3D, scores, corners, Kmat, min_votes=1, ctx=ctx)  # occlusion_eval.py:359-371
+    assert [(o["image"], o["cls"]) for o in one] == [(0, 0), (0, 2), (1, 1), (1, 2)]
