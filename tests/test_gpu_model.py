@@ -296,6 +296,36 @@ def test_data_parallel_path_single_rank_nccl(ctx):
         dist.destroy_process_group()
 
 
+def test_two_rank_data_parallel_equals_global_batch(ctx, tmp_path):
+    """two ranks with two images each (count exchange + bucketed gradient all-reduce, gloo here because the
+    ranks share the box's one GPU) must take the step a single process takes on the global batch of four: same positive
+    counts, same summed gradient, same weights after clipnorm-Adam, and rank-wise loss shares that add up."""
+    import os
+    import subprocess
+    import sys
+    from pyrapose_amd.engine import Engine
+    from tests.dp_worker import global_batch
+    B, H, W, C, Wt, x, tg = global_batch()
+    eng = Engine(ctx, C, B, H, W, weights=Wt, train=True)
+    eng.train_step(torch.from_numpy(x).cuda(), [torch.from_numpy(a).cuda() for a in tg])
+    torch.cuda.synchronize()
+    g_ref, w_ref, counts_ref = eng.params.grad.cpu().numpy(), eng.params.w_master.cpu().numpy(), eng.counts.cpu().numpy()
+    l_ref = np.array([eng.losses()[k] for k in ("3Dbox", "cls", "mask")])
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="2", HSA_ENABLE_IPC_MODE_LEGACY="0")  # two ranks on one card (DESIGN.md 5.1)
+    worker = os.path.join(os.path.dirname(__file__), "dp_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", "29541", str(tmp_path)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    r0, r1 = (np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(2))
+    assert np.array_equal(r0["counts"], counts_ref) and np.array_equal(r1["counts"], counts_ref)
+    assert np.array_equal(r0["grad"], r1["grad"]) and np.array_equal(r0["w"], r1["w"])  # replicas stay identical
+    scale = np.abs(g_ref).max()
+    assert np.abs(r0["grad"] - g_ref).max() <= 2e-5 * scale, np.abs(r0["grad"] - g_ref).max() / scale
+    assert np.abs(r0["w"] - w_ref).max() <= 1e-7 * np.abs(w_ref).max() + 1e-9
+    assert np.allclose(r0["losses"] + r1["losses"], l_ref, rtol=1e-5, atol=1e-7)
+
+
 def test_forward_tless_720x540_c30_vs_oracle(ctx):
     """BASELINE configs[4] geometry: 720x540, 30 classes -> levels 68x90 / 34x45 / 17x23 (odd extents: TF 'same'
     pads (1,1) on the stride-2 convs, nearest upsample 23 -> 45 is not x2), N = 72369 anchors."""
