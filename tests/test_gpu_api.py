@@ -151,3 +151,50 @@ def test_preprocess_u8_matches_reference_preprocessing():
         assert torch.equal(p, q)
     with pytest.raises(ValueError):
         ops.preprocess_caffe_u8(ctx, torch.from_numpy(u8).cuda(), [(65, 96)] * B, x4)
+
+
+def test_fit_generator_prefetch_matches_synchronous_loop():
+    """fit_generator(workers=1): batches are uploaded ahead of the step by pyrapose_amd/prefetch.py and the losses stay on
+    the device; the epoch losses and the trained weights must equal those of the synchronous path (workers=0)."""
+    import numpy as np
+    import torch
+    from pyrapose_amd import losses, models, optimizers
+    from pyrapose_amd.prefetch import DevicePrefetcher
+
+    class Gen(object):  # preprocessing/generator.py:384-398 contract
+        def __init__(self, n, B, H, W, C, N, M):
+            rng = np.random.default_rng(3)
+            self.b = []
+            for _ in range(n):
+                x = (rng.integers(0, 256, (B, H, W, 3)).astype(np.float32) - 110.0)
+                yb = rng.standard_normal((B, N, 17)).astype(np.float32); yb[:, :, 16] = (rng.uniform(size=(B, N)) < 0.03)
+                yc = np.zeros((B, N, C + 1), np.float32); st = (rng.uniform(size=(B, N)) < 0.03); yc[:, :, C] = st
+                yc[:, :, 1] = st
+                ym = np.zeros((B, M, C + 1), np.float32); sm = (rng.uniform(size=(B, M)) < 0.05); ym[:, :, C] = sm; ym[:, :, 0] = sm
+                self.b.append((x, [yb, yc, ym]))
+
+        def __len__(self):
+            return len(self.b)
+
+        def __getitem__(self, i):
+            return self.b[i]
+
+    B, H, W, C = 2, 64, 96, 4
+    N = sum(((H + 2 ** l - 1) // 2 ** l) * ((W + 2 ** l - 1) // 2 ** l) for l in (3, 4, 5)) * 9
+    gen = Gen(5, B, H, W, C, N, ((H + 7) // 8) * ((W + 7) // 8))
+    # the uploader hands out the generator's batches in order, bit for bit
+    for i, (xd, yd) in enumerate(DevicePrefetcher(lambda i: gen[i % len(gen)], 7, depth=3)):
+        x, ys = gen[i % len(gen)]
+        assert torch.equal(xd.cpu(), torch.from_numpy(x)) and all(torch.equal(a.cpu(), torch.from_numpy(b)) for a, b in zip(yd, ys))
+    assert i == 6
+    results = []
+    for workers in (0, 1):
+        m = models.backbone("resnet50").retinanet(num_classes=C)
+        m.compile(loss={"3Dbox": losses.orthogonal_l1(), "cls": losses.focal(), "mask": losses.focal()},
+                  optimizer=optimizers.Adam(lr=1e-4, clipnorm=0.001))
+        h = m.fit_generator(gen, steps_per_epoch=5, epochs=2, verbose=0, workers=workers, max_queue_size=3)
+        results.append((h["loss"], m.get_weights_dict()))
+    (l0, w0), (l1, w1) = results
+    assert np.allclose(l0, l1, rtol=1e-5, atol=1e-6), (l0, l1)
+    for k in w0:
+        assert np.abs(w0[k] - w1[k]).max() <= 1e-6 * max(np.abs(w0[k]).max(), 1e-3), k
