@@ -251,7 +251,7 @@ def main():
                 tj = json.load(f)
             traffic = tj.get(mode)
         if mode == "bf16x3":
-            peak, kname = PEAK_BF16_MFMA_TFLOPS, "conv implicit-GEMM family (igemm3f fwd/bwd-data + wgrad3f): 3 x v_mfma_f32_32x32x16_bf16 per product, f32 accumulate"
+            peak, kname = PEAK_BF16_MFMA_TFLOPS, "conv implicit-GEMM family (igemm3x / igemm3f fwd + bwd-data, wgrad3f): 3 x v_mfma_f32_32x32x16_bf16 per product, f32 accumulate"
         else:
             peak, kname = PEAK_F32_MFMA_TFLOPS, "conv implicit-GEMM family (igemm fwd/bwd-data + wgrad): v_mfma_f32_32x32x2_f32"
         roofline = {"bound": "mfma", "achieved": roof["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": roof["achieved"] / peak,
