@@ -51,6 +51,18 @@ int pp_ctx_set_workspace(pp_ctx* ctx, void* device_buffer, size_t bytes);
  * untouched).  The kernel has the converted values in registers anyway; the weight-gradient launch of the same layer
  * (pp_conv2d_nhwc_bwd_weight_bf16x3 with all four planes) then skips its own conversion.  NULL, NULL cancels. */
 int pp_ctx_set_split_capture(pp_ctx* ctx, void* hi, void* lo);
+/* Row-block skip for sparse gradients.  The 3D-box loss (losses.py:321-408, orthogonal_l1) keeps only the rows with anchor
+ * state 1, so the gradient that flows back through the 3D-box head is exactly zero away from the positive anchors (and
+ * stays so layer after layer, dilated by one pixel per 3x3 conv).  pp_row_block_list scans a gradient tensor x [rows][ld]
+ * (first `cols` columns) once: flags[b] = 1 when the 32-row block b holds a non-zero (or a NaN), list = {count, the flagged
+ * block indices ascending} (flags: ceil(rows/32) bytes, list: 1 + ceil(rows/32) ints, device memory).
+ * pp_ctx_set_row_block_skip is one-shot: the NEXT pp_conv2d_nhwc_bwd_weight_bf16x3 call on this context (float32 operands)
+ * reduces over the listed blocks of dy only, the NEXT pp_conv2d_nhwc_bwd_data_bf16x3 call (3x3, stride 1) skips the
+ * reduction of output tiles none of whose reachable dy blocks is flagged (the epilogue still applies addend / mask).  A
+ * block of zero rows contributes exactly 0.0 to every sum: the results are those of the dense launch (up to the order of
+ * the float32 atomics between reduction splits).  Launches that cannot use the hint run dense.  NULL, NULL cancels. */
+int pp_row_block_list(pp_ctx* ctx, const float* x, int rows, int ld, int cols, unsigned char* flags, int* list);
+int pp_ctx_set_row_block_skip(pp_ctx* ctx, const unsigned char* flags, const int* list);
 const char* pp_last_error_string(pp_ctx* ctx);
 const char* pp_version(void);
 /* number of compute units / name of the device the ctx is bound to (for bench metadata) */

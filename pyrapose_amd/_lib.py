@@ -85,6 +85,8 @@ _SIGS = {
     "pp_split_planes_bf16x3": (_i, [_p, _sz, _p, _p, _p]),
     "pp_ctx_set_workspace": (_i, [_p, _p, C.c_size_t]),
     "pp_ctx_set_split_capture": (_i, [_p, _p, _p]),
+    "pp_row_block_list": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    "pp_ctx_set_row_block_skip": (_i, [_p, _p, _p]),
     "pp_conv_split_weights_bf16x3_batch": (_i, [_p, _i, _p, _i]),
     "pp_conv2d_nhwc_fwd_bf16x3": (_i, [_p, C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "pp_conv2d_nhwc_bwd_data_bf16x3": (_i, [_p, C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p]),

@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3x_kernel(
     const IgemmParams p, const void* __restrict__ g_a, unsigned a_bytes, const void* __restrict__ g_whi, const void* __restrict__ g_wlo,
     unsigned w_bytes, const float* __restrict__ g_bias, const float* __restrict__ g_addend, const float* __restrict__ g_mask,
     float* __restrict__ g_out, int w_rows, int w_ld8, int splits, float* __restrict__ g_ws, void* __restrict__ g_chi,
-    void* __restrict__ g_clo) {
+    void* __restrict__ g_clo, const unsigned char* __restrict__ g_flags, int skip_halo) {
   constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, NO = BK / 8;
   constexpr int AP1 = NO * BM + 1;  // plane size: the tile + one all-zero slot that padded taps read instead of their row
   constexpr int SMEM_U4 = 2 * AP1 + 2 * NO * BN;
@@ -597,7 +597,19 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3x_kernel(
   const int il = lane & 31, h = lane >> 5;
   const int n_chunks = p.Cred / BK;
   const int all_groups = p.kh * n_chunks;  // one group = the three taps of (ty, chunk)
-  const int g_begin = (int)((long long)all_groups * split / splits), g_end = (int)((long long)all_groups * (split + 1) / splits);
+  const int g_begin = (int)((long long)all_groups * split / splits);
+  int g_end = (int)((long long)all_groups * (split + 1) / splits);
+  if (g_flags) {
+    // row-block skip (pp_ctx_set_row_block_skip): when none of the 32-row blocks of the gathered tensor that this tile can
+    // reach (its rows +- one image row +- one pixel; skip_halo = widest level + 1) holds a non-zero, the sum is exactly
+    // zero: no k-loop, the epilogue still writes bias / addend / mask.  Workgroup-uniform.
+    int lo = m0 - skip_halo, hi = m0 + BM - 1 + skip_halo;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > p.M - 1 ? p.M - 1 : hi;
+    int any = 0;
+    for (int b = lo >> 5; b <= (hi >> 5); ++b) any |= g_flags[b];
+    g_end = any ? g_end : g_begin;
+  }
 
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_a), 0, a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_whi), 0, w_bytes, 0x00020000);
@@ -881,6 +893,56 @@ __global__ void split_planes_kernel(size_t n8, const float4* __restrict__ src, u
   }
 }
 
+// ---- which 32-row blocks of a gradient tensor hold a non-zero? (input of the row-block skip of bwd-weight / bwd-data) ----
+__global__ void row_block_flags_kernel(const float* __restrict__ x, int rows, int ld, int cols4, unsigned char* __restrict__ flags) {
+  const int blk = blockIdx.x, r0 = blk * 32;
+  const int nr = rows - r0 < 32 ? rows - r0 : 32;
+  int any = 0;
+  for (int i = threadIdx.x; i < nr * cols4; i += blockDim.x) {
+    const int r = i / cols4, c = i - r * cols4;
+    const float4 v = *reinterpret_cast<const float4*>(x + (long long)(r0 + r) * ld + 4 * c);
+    any |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);  // NaN != 0: a block with a NaN is kept
+  }
+  any = __syncthreads_or(any);
+  if (threadIdx.x == 0) flags[blk] = any ? 1 : 0;
+}
+
+// ordered compaction by ONE workgroup: list[0] = count, list[1 ..] = the flagged block indices, ascending
+__global__ void row_block_compact_kernel(const unsigned char* __restrict__ flags, int n_blocks, int* __restrict__ list) {
+  __shared__ int wave_cnt[4];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n_blocks; i0 += 256) {
+    const int i = i0 + tid;
+    const bool f = i < n_blocks && flags[i] != 0;
+    const unsigned long long m = __ballot(f);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (f) list[1 + off + before] = i;
+    __syncthreads();
+    if (tid == 0) base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  if (tid == 0) list[0] = base;
+}
+
+extern "C" int pp_row_block_list(pp_ctx* ctx, const float* x, int rows, int ld, int cols, unsigned char* flags, int* list) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, x && flags && list && rows > 0 && cols > 0 && cols <= ld && ld % 4 == 0 && pp_is_aligned16(x), PP_ERR_ARG,
+               "pp_row_block_list: bad tensor (ld %% 4 == 0, 16-byte aligned)");
+  const int nb = (rows + 31) / 32, cols4 = (cols + 3) / 4;
+  PP_CHECK_ARG(ctx, 4 * cols4 <= ld, PP_ERR_SHAPE, "pp_row_block_list: cols rounded up to 4 exceed ld");
+  hipLaunchKernelGGL(row_block_flags_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, x, rows, ld, cols4, flags);
+  hipLaunchKernelGGL(row_block_compact_kernel, dim3(1), dim3(256), 0, ctx->stream, (const unsigned char*)flags, nb, list);
+  PP_CHECK_LAUNCH(ctx, "pp_row_block_list");
+  return PP_OK;
+}
+
 extern "C" int pp_split_planes_bf16x3(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo) {
   PP_REQUIRE_CTX(ctx);
   PP_CHECK_ARG(ctx, src && hi && lo && n % 8 == 0, PP_ERR_ARG, "pp_split_planes_bf16x3: n must be a multiple of 8");
@@ -1000,7 +1062,8 @@ static void split_capture_pass(hipStream_t st, const IgemmParams& p, void* chi, 
 // tap-row-reuse kernel where that one runs, by a separate pass over the operand otherwise
 template <int TM, int TN>
 static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const void* alo, const void* whi, const void* wlo, int w_rows,
-                          int w_ld8, void* ohi, void* olo, int splits, float* ws, void* chi = nullptr, void* clo = nullptr) {
+                          int w_ld8, void* ohi, void* olo, int splits, float* ws, void* chi = nullptr, void* clo = nullptr,
+                          const unsigned char* flags = nullptr) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   p.n_tiles_n = (p.Nout + BN - 1) / BN;
   const int n_tiles_m = (p.M + BM - 1) / BM;
@@ -1021,13 +1084,16 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
       same = p.seg[i].OH == p.seg[i].SH && p.seg[i].OW == p.seg[i].SW && p.seg[i].row_begin == p.seg[i].src_row_begin;
     if (same) {
       const int n_tiles_mx = (p.M + BM - 3) / (BM - 2);  // tiles overlap by two rows
+      int skip_halo = 0;
+      for (int i = 0; i < p.n_seg; ++i) skip_halo = p.seg[i].SW + 1 > skip_halo ? p.seg[i].SW + 1 : skip_halo;
       const dim3 gridx((unsigned)(n_tiles_mx * p.n_tiles_n * splits));
       if (chi)
         hipLaunchKernelGGL((igemm3x_kernel<TM, TN, true>), gridx, dim3(256), 0, st, p, (const void*)p.src, (unsigned)a_bytes, whi, wlo,
-                           (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, w_rows, w_ld8, splits, ws, chi, clo);
+                           (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, w_rows, w_ld8, splits, ws, chi, clo, flags, skip_halo);
       else
         hipLaunchKernelGGL((igemm3x_kernel<TM, TN, false>), gridx, dim3(256), 0, st, p, (const void*)p.src, (unsigned)a_bytes, whi, wlo,
-                           (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, w_rows, w_ld8, splits, ws, nullptr, nullptr);
+                           (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, w_rows, w_ld8, splits, ws, nullptr, nullptr, flags,
+                           skip_halo);
       return;
     }
   }
@@ -1096,18 +1162,18 @@ static void pick_tile3(const pp_ctx* ctx, int M, int Nout, int ld_out, int n_ste
 }
 
 static void dispatch3(pp_ctx* ctx, IgemmParams& p, const void* ahi, const void* alo, const void* whi, const void* wlo, int w_rows,
-                      int w_ld8, void* ohi, void* olo, void* chi = nullptr, void* clo = nullptr) {
+                      int w_ld8, void* ohi, void* olo, void* chi = nullptr, void* clo = nullptr, const unsigned char* flags = nullptr) {
   int tm, tn, splits;
   const int n_steps = p.kh * p.kw * (p.Cred / 32);
   const bool may_split = ctx->ws != nullptr && !ohi && p.out != nullptr && !p.sc_on && igemm3_fast_ok(p, ahi != nullptr, w_rows, w_ld8);
   pick_tile3(ctx, p.M, p.Nout, p.ld_out, n_steps, may_split, &tm, &tn, &splits);
   if (getenv("PP_CONV_DEBUG")) fprintf(stderr, "igemm3 M %d N %d steps %d -> tile %dx%d splits %d\n", p.M, p.Nout, n_steps, 64 * tm, 64 * tn, splits);
   float* ws = splits > 1 ? ctx->ws : nullptr;
-  if (tm == 4) launch_igemm3<4, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo);
-  else if (tm == 2 && tn == 2) launch_igemm3<2, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo);
-  else if (tm == 1 && tn == 2) launch_igemm3<1, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo);
-  else if (tm == 2 && tn == 1) launch_igemm3<2, 1>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo);
-  else launch_igemm3<1, 1>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo);
+  if (tm == 4) launch_igemm3<4, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo, flags);
+  else if (tm == 2 && tn == 2) launch_igemm3<2, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo, flags);
+  else if (tm == 1 && tn == 2) launch_igemm3<1, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo, flags);
+  else if (tm == 2 && tn == 1) launch_igemm3<2, 1>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo, flags);
+  else launch_igemm3<1, 1>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo, flags);
   if (splits > 1) {
     const long long total = (long long)p.M * ((p.Nout + 3) >> 2);
     long long blocks = (total + 255) / 256;
@@ -1194,6 +1260,9 @@ extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d
   PP_REQUIRE_CTX(ctx);
   void *chi = ctx->cap_hi, *clo = ctx->cap_lo;  // one-shot (pp_ctx_set_split_capture)
   ctx->cap_hi = ctx->cap_lo = nullptr;
+  const unsigned char* skip_flags = ctx->skip_flags;  // one-shot (pp_ctx_set_row_block_skip)
+  ctx->skip_flags = nullptr;
+  ctx->skip_list = nullptr;
   int rc = check_desc(ctx, d, "pp_conv2d_nhwc_bwd_data_bf16x3");
   if (rc) return rc;
   PP_CHECK_ARG(ctx, !chi || (dy && !dy_hi), PP_ERR_ARG, "pp_conv2d_nhwc_bwd_data_bf16x3: split capture needs the f32 operand");
@@ -1266,7 +1335,7 @@ extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d
       return PP_OK;
     }
   }
-  dispatch3(ctx, p, dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8, dx_hi, dx_lo, chi, clo);
+  dispatch3(ctx, p, dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8, dx_hi, dx_lo, chi, clo, dy_hi ? nullptr : skip_flags);
   PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_data_bf16x3");
   return PP_OK;
 }
@@ -1562,12 +1631,16 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 2 : 3) void wgrad3_kernel(con
 // operands with 32-bit buffer offsets (out-of-range = zeros: padding taps, rows past the split, columns past ld_dy)
 // and converts the loaded tile while its MFMAs drain.  No 64-bit address registers -> 3 workgroups per CU at 128x128.
 
-template <int TM, int TN, bool AP>
+// SP: the reduction walks a LIST of 32-row blocks (pp_row_block_list: the blocks of dy that hold a non-zero) instead of all
+// rows -- the gradient of the 3D-box head is non-zero only around positive anchors (losses.py:332-333 keeps state == 1
+// rows), and a block of zero rows adds exactly nothing to dW.  list[0] = number of blocks, list[1..] ascending; the
+// splits share the list evenly, so the launch stays balanced whatever the data.
+template <int TM, int TN, bool AP, bool SP>
 __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(const Wgrad3Params p, const void* __restrict__ g_x0,
                                                                             const void* __restrict__ g_x1, unsigned x_bytes,
                                                                             const void* __restrict__ g_d0, const void* __restrict__ g_d1,
                                                                             unsigned d_bytes, float* __restrict__ g_dw,
-                                                                            float* __restrict__ g_dbias) {
+                                                                            float* __restrict__ g_dbias, const int* __restrict__ g_list) {
   constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32;
   constexpr int PA = BM + 32, PB = BN + 32;  // LDS pitches in bf16 elements (row + 64 bytes)
   constexpr int ES = AP ? 2 : 4;
@@ -1588,9 +1661,19 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
   const int ci0 = (tile_k - tap * p.k_tiles_per_tap) * BM;
   const int ty = tap / p.kw, tx = tap - ty * p.kw;
   const int n0 = tile_n * BN;
-  const int m_begin = split * p.rows_per_split;
-  const int m_end = min(p.M, m_begin + p.rows_per_split);
-  const int n_steps = (m_end - m_begin + BK - 1) / BK;
+  int m_begin = split * p.rows_per_split;
+  int m_end = min(p.M, m_begin + p.rows_per_split);
+  int n_steps = (m_end - m_begin + BK - 1) / BK;
+  int s_idx = 0, s_end = 0;
+  const int blk_past = (p.M + BK - 1) / BK;  // SP: "no more blocks" (its rows are >= M: loads return zeros)
+  if (SP) {
+    const int n_act = g_list[0];
+    s_idx = (int)((long long)n_act * split / p.splits);
+    s_end = (int)((long long)n_act * (split + 1) / p.splits);
+    n_steps = s_end - s_idx;
+    m_begin = (n_steps > 0 ? g_list[1 + s_idx] : blk_past) * BK;
+    m_end = p.M;
+  }
 
   const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_x0), 0, x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(AP ? g_x1 : g_x0), 0, x_bytes, 0x00020000);
@@ -1659,6 +1742,12 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
     }
   };
   auto next_row = [&]() {  // m_cur += 32
+    if (SP) {  // jump to the next listed block: full decode (two reciprocal divisions per step)
+      ++s_idx;
+      m_cur = (s_idx < s_end ? g_list[1 + s_idx] : blk_past) * BK + prow;
+      decode(m_cur);
+      return;
+    }
     m_cur += BK;
     if (__builtin_amdgcn_ballot_w64(m_cur >= c_end) != 0) {
       decode(m_cur);
@@ -1832,7 +1921,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
 
 template <int TM, int TN>
 static void launch_wgrad3(pp_ctx* ctx, Wgrad3Params& p, const float* x, const float* dy, const void* xhi, const void* xlo, const void* dhi,
-                          const void* dlo, float* dw, float* dbias) {
+                          const void* dlo, float* dw, float* dbias, const int* list = nullptr) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   p.k_tiles_per_tap = p.Cin / BM;
   p.n_tiles_k = p.kh * p.kw * p.k_tiles_per_tap;
@@ -1879,11 +1968,14 @@ static void launch_wgrad3(pp_ctx* ctx, Wgrad3Params& p, const float* x, const fl
   p.rows_per_split = rps;
   if (fast) {
     if (xhi)
-      hipLaunchKernelGGL((wgrad3f_kernel<TM, TN, true>), dim3((unsigned)(tiles * splits)), dim3(256), 0, ctx->stream, p, xhi, xlo,
-                         (unsigned)x_bytes, dhi, dlo, (unsigned)d_bytes, dw, dbias);
+      hipLaunchKernelGGL((wgrad3f_kernel<TM, TN, true, false>), dim3((unsigned)(tiles * splits)), dim3(256), 0, ctx->stream, p, xhi, xlo,
+                         (unsigned)x_bytes, dhi, dlo, (unsigned)d_bytes, dw, dbias, (const int*)nullptr);
+    else if (list)
+      hipLaunchKernelGGL((wgrad3f_kernel<TM, TN, false, true>), dim3((unsigned)(tiles * splits)), dim3(256), 0, ctx->stream, p, (const void*)x,
+                         nullptr, (unsigned)x_bytes, (const void*)dy, nullptr, (unsigned)d_bytes, dw, dbias, list);
     else
-      hipLaunchKernelGGL((wgrad3f_kernel<TM, TN, false>), dim3((unsigned)(tiles * splits)), dim3(256), 0, ctx->stream, p, (const void*)x,
-                         nullptr, (unsigned)x_bytes, (const void*)dy, nullptr, (unsigned)d_bytes, dw, dbias);
+      hipLaunchKernelGGL((wgrad3f_kernel<TM, TN, false, false>), dim3((unsigned)(tiles * splits)), dim3(256), 0, ctx->stream, p, (const void*)x,
+                         nullptr, (unsigned)x_bytes, (const void*)dy, nullptr, (unsigned)d_bytes, dw, dbias, (const int*)nullptr);
   } else if (xhi)
     hipLaunchKernelGGL((wgrad3_kernel<TM, TN, true>), dim3((unsigned)(tiles * splits)), dim3(256), 0, ctx->stream, p, x, dy, (const uint4*)xhi,
                        (const uint4*)xlo, (const uint4*)dhi, (const uint4*)dlo, dw, dbias);
@@ -1895,6 +1987,9 @@ static void launch_wgrad3(pp_ctx* ctx, Wgrad3Params& p, const float* x, const fl
 extern "C" int pp_conv2d_nhwc_bwd_weight_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const float* dy, const void* x_hi,
                                                 const void* x_lo, const void* dy_hi, const void* dy_lo, float* dw, float* dbias) {
   PP_REQUIRE_CTX(ctx);
+  const int* skip_list = ctx->skip_list;  // one-shot (pp_ctx_set_row_block_skip)
+  ctx->skip_list = nullptr;
+  ctx->skip_flags = nullptr;
   int rc = check_desc(ctx, d, "pp_conv2d_nhwc_bwd_weight_bf16x3");
   if (rc) return rc;
   const bool planes = x_hi && x_lo && dy_hi && dy_lo;
@@ -1923,10 +2018,10 @@ extern "C" int pp_conv2d_nhwc_bwd_weight_bf16x3(pp_ctx* ctx, const pp_conv_desc*
       big_n = e[2] == '2';
     }
   }
-  if (big_k && big_n) launch_wgrad3<2, 2>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias);
-  else if (big_k) launch_wgrad3<2, 1>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias);
-  else if (big_n) launch_wgrad3<1, 2>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias);
-  else launch_wgrad3<1, 1>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias);
+  if (big_k && big_n) launch_wgrad3<2, 2>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias, planes ? nullptr : skip_list);
+  else if (big_k) launch_wgrad3<2, 1>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias, planes ? nullptr : skip_list);
+  else if (big_n) launch_wgrad3<1, 2>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias, planes ? nullptr : skip_list);
+  else launch_wgrad3<1, 1>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias, planes ? nullptr : skip_list);
   PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_weight_bf16x3");
   return PP_OK;
 }

@@ -54,6 +54,13 @@ extern "C" int pp_ctx_set_split_capture(pp_ctx* ctx, void* hi, void* lo) {
   return PP_OK;
 }
 
+extern "C" int pp_ctx_set_row_block_skip(pp_ctx* ctx, const unsigned char* flags, const int* list) {
+  PP_REQUIRE_CTX(ctx);
+  ctx->skip_flags = flags;
+  ctx->skip_list = list;
+  return PP_OK;
+}
+
 extern "C" const char* pp_last_error_string(pp_ctx* ctx) { return ctx ? ctx->err : "no context"; }
 
 extern "C" int pp_device_info(pp_ctx* ctx, int* n_cu, char* name, int name_len) {

@@ -17,6 +17,8 @@ struct pp_ctx {
   size_t ws_bytes;
   void* cap_hi;     // one-shot: the next bf16x3 fwd / bwd-data launch also writes the split of its gathered operand here
   void* cap_lo;
+  const int* skip_list;              // one-shot: row-block skip of the next bf16x3 bwd-weight (list) / bwd-data (flags) call
+  const unsigned char* skip_flags;
 };
 
 static inline int pp_fail(pp_ctx* ctx, int code, const char* fmt, ...) {

@@ -213,6 +213,13 @@ class Engine(object):
         # 11-15 % and the capture costs the 512-channel launches nothing, but the training step does not move (one lane:
         # +0.6 %; two lanes: -1 % -- with both lanes busy the MFMA pipes, not the conversion VALU, are what is shared).
         self.capture = (self.conv_mode == "bf16x3" and not self.use_act_planes and _os.environ.get("PP_CAPTURE", "0") == "1")
+        # Sparse backward of the 3D-box head (PP_SPARSE_BWD=0 disables): orthogonal_l1 keeps the rows with anchor state 1 only
+        # (losses.py:332-333), so the gradient entering that head -- and, dilated by one pixel per 3x3 layer, every gradient
+        # inside it -- is exactly zero away from the positive anchors.  One scan per layer lists the 32-row blocks that hold a
+        # non-zero (pp_row_block_list); the weight gradient reduces over those blocks only and the data gradient skips the
+        # output tiles that cannot see one.  Exact: a zero row adds 0.0 to every sum.
+        self.sparse_bwd = tuple(t for t in _os.environ.get("PP_SPARSE_BWD", "reg").split(",") if t and t != "0") \
+            if self.conv_mode == "bf16x3" and not self.use_act_planes else ()
         self.capture_min_cin = int(_os.environ.get("PP_CAPTURE_MIN_CIN", "64"))
         self.capture_skip = tuple(t for t in _os.environ.get("PP_CAPTURE_SKIP", "").split(",") if t)
         self.planes = OrderedDict()  # spec name -> dict(desc, fwd_hi, fwd_lo, dg_hi, dg_lo)
@@ -368,7 +375,10 @@ class Engine(object):
     def _wants_capture(self, s, x):
         return (self.train and self.capture and s.trainable and x.needs_grad and s.k == 3 and s.stride == 1 and (s.pad == "same" or str(s.pad) == "1")
                 and s.cin % 64 == 0 and s.cout % 32 == 0 and s.cin >= self.capture_min_cin and x.ld % 8 == 0 and x.pl is None
-                and not any(s.name.startswith(t) for t in self.capture_skip))
+                and not any(s.name.startswith(t) for t in self.capture_skip) and not self._sparse_layer(s))
+
+    def _sparse_layer(self, s):
+        return self.train and s.k == 3 and s.stride == 1 and s.cin % 64 == 0 and any(s.name.startswith(t) for t in self.sparse_bwd)
 
     def _wants_planes(self, s):
         # worth it only where the weight-gradient launch is big and conversion-bound: the wide 3x3 convs (regression head)
@@ -635,8 +645,9 @@ class Engine(object):
                     opl = _new_planes(act.rows, act.ld)
                 out = None if (opl is not None and planes_only) else new()
                 gcap = op.get("g_cap")
-                self.bwd_ops.append(Op(lambda d=op["desc"], gy=gy, dh=pl["dg_hi"], dl=pl["dg_lo"], acc=acc, mask=mask, out=out, opl=opl, gcap=gcap:
-                                       ops.conv_bwd_data3(ctx, d, gy.t, dh, dl, acc, mask, out, gy.pl, opl, gcap), "conv_dgrad",
+                sk = op.get("skip") if gy.pl is None else None
+                self.bwd_ops.append(Op(lambda d=op["desc"], gy=gy, dh=pl["dg_hi"], dl=pl["dg_lo"], acc=acc, mask=mask, out=out, opl=opl, gcap=gcap, sk=sk:
+                                       ops.conv_bwd_data3(ctx, d, gy.t, dh, dl, acc, mask, out, gy.pl, opl, gcap, sk), "conv_dgrad",
                                        op["spec"].name, op["flops"]))
                 pw = op.pop("pending_wgrad", None)
                 if pw is not None:  # the layer's weight gradient reads the planes this launch has just written
@@ -681,6 +692,13 @@ class Engine(object):
                 continue
             if kind == "conv":
                 s, x = op["spec"], op["x"]
+                if self._sparse_layer(s) and g.pl is None and g.t.is_contiguous() and g.t.dim() == 2:
+                    nb = (g.t.shape[0] + 31) // 32
+                    skip = op["skip"] = (torch.zeros((nb,), dtype=torch.uint8, device="cuda"),
+                                         torch.zeros((nb + 1,), dtype=torch.int32, device="cuda"))
+                    cols = min((y.C + 3) // 4 * 4, g.t.shape[1])
+                    self.bwd_ops.append(Op(lambda gt=g.t, cols=cols, skip=skip: ops.row_block_list(ctx, gt, cols, skip[0], skip[1]),
+                                           "pointwise", "rowblocks:" + s.name))
                 if s.trainable:
                     dw = P.view(P.grad, s.name + "/kernel")
                     db = P.view(P.grad, s.name + "/bias") if s.bias else None
@@ -699,8 +717,9 @@ class Engine(object):
                         fn = None
                     elif self.conv_mode == "bf16x3" and s.cin % 64 == 0:
                         both = x.pl is not None and g.pl is not None
-                        fn = lambda d=op["desc"], x=x, g=g, dw=dw, db=db, wctx=wctx, xp=(x.pl if both else None), gp=(g.pl if both else None): \
-                            ops.conv_bwd_weight3(wctx, d, x.t, g.t, dw, db, xp, gp)
+                        sk = None if both else op.get("skip")
+                        fn = lambda d=op["desc"], x=x, g=g, dw=dw, db=db, wctx=wctx, xp=(x.pl if both else None), gp=(g.pl if both else None), sk=sk: \
+                            ops.conv_bwd_weight3(wctx, d, x.t, g.t, dw, db, xp, gp, sk)
                     else:
                         fn = lambda d=op["desc"], xt=x.t, g=g, dw=dw, db=db, wctx=wctx: ops.conv_bwd_weight(wctx, d, xt, g.t, dw, db)
                     if fn is not None:

@@ -121,6 +121,23 @@ def _set_capture(ctx, planes):
         check(lib.pp_ctx_set_split_capture(ctx.handle, _ptr(planes[0]), _ptr(planes[1])), ctx.handle, "pp_ctx_set_split_capture")
 
 
+def row_block_list(ctx, x, cols, flags=None, blocks=None):
+    """pp_row_block_list: x float32 [rows, ld] -> (flags uint8 [nb], list int32 [1 + nb]) with nb = ceil(rows / 32)."""
+    rows, ld = x.shape
+    nb = (rows + 31) // 32
+    if flags is None:
+        flags = torch.empty((nb,), dtype=torch.uint8, device=x.device)
+    if blocks is None:
+        blocks = torch.empty((nb + 1,), dtype=torch.int32, device=x.device)
+    check(lib.pp_row_block_list(ctx.handle, _ptr(x), rows, x.stride(0), int(cols), _ptr(flags), _ptr(blocks)), ctx.handle, "pp_row_block_list")
+    return flags, blocks
+
+
+def _set_skip(ctx, skip):
+    if skip is not None:
+        check(lib.pp_ctx_set_row_block_skip(ctx.handle, _ptr(skip[0]), _ptr(skip[1])), ctx.handle, "pp_ctx_set_row_block_skip")
+
+
 def conv_fwd3(ctx, d, x, w_hi, w_lo, bias, residual, relu, y, x_planes=None, y_planes=None, x_capture=None):
     """x_capture = (hi, lo): the launch also writes the bf16 split of x (pp_ctx_set_split_capture)."""
     _set_capture(ctx, x_capture)
@@ -132,9 +149,11 @@ def conv_fwd3(ctx, d, x, w_hi, w_lo, bias, residual, relu, y, x_planes=None, y_p
           "pp_conv2d_nhwc_fwd_bf16x3")
 
 
-def conv_bwd_data3(ctx, d, dy, w_hi, w_lo, addend, relu_src, dx, dy_planes=None, dx_planes=None, dy_capture=None):
-    """dy_capture = (hi, lo): the launch also writes the bf16 split of dy (pp_ctx_set_split_capture)."""
+def conv_bwd_data3(ctx, d, dy, w_hi, w_lo, addend, relu_src, dx, dy_planes=None, dx_planes=None, dy_capture=None, dy_skip=None):
+    """dy_capture = (hi, lo): the launch also writes the bf16 split of dy (pp_ctx_set_split_capture).
+    dy_skip = (flags, list) from row_block_list(dy): tiles that only see zero blocks of dy skip their reduction."""
     _set_capture(ctx, dy_capture)
+    _set_skip(ctx, dy_skip)
     ld_add = addend.stride(0) if addend is not None else 0
     ld_rs = relu_src.stride(0) if relu_src is not None else 0
     dh, dl = dy_planes if dy_planes is not None else (None, None)
@@ -144,7 +163,9 @@ def conv_bwd_data3(ctx, d, dy, w_hi, w_lo, addend, relu_src, dx, dy_planes=None,
           "pp_conv2d_nhwc_bwd_data_bf16x3")
 
 
-def conv_bwd_weight3(ctx, d, x, dy, dw, dbias, x_planes=None, dy_planes=None):
+def conv_bwd_weight3(ctx, d, x, dy, dw, dbias, x_planes=None, dy_planes=None, dy_skip=None):
+    """dy_skip = (flags, list) from row_block_list(dy): the reduction walks the listed 32-row blocks only."""
+    _set_skip(ctx, dy_skip)
     xh, xl = x_planes if x_planes is not None else (None, None)
     dh, dl = dy_planes if dy_planes is not None else (None, None)
     check(lib.pp_conv2d_nhwc_bwd_weight_bf16x3(ctx.handle, C.byref(d), _ptr(x), _ptr(dy), _ptr(xh), _ptr(xl), _ptr(dh), _ptr(dl),

@@ -471,3 +471,47 @@ def test_conv_bf16x3_split_k(ctx, splits, monkeypatch):
     assert rel_err(y2.cpu().numpy(), y1.cpu().numpy()) < 2e-6
     assert rel_err(dx2.cpu().numpy(), dx1.cpu().numpy()) < 2e-6
     assert not torch.equal(y1, torch.zeros_like(y1))
+
+
+@pytest.mark.parametrize("frac", [0.0, 0.03, 1.0])
+def test_row_block_skip_matches_dense(ctx, frac):
+    """Sparse gradients (3D-box head: non-zero only around positive anchors): bwd-weight over the listed 32-row blocks of dy
+    and bwd-data with tile skipping give the dense results -- a block of zero rows adds exactly 0.0."""
+    from pyrapose_amd import ops
+    rng = np.random.default_rng(17)
+    B, shapes, cin, cout, k = 2, [(20, 26), (10, 13), (5, 7)], 128, 64, 3
+    rows = sum(B * h * w for h, w in shapes)
+    d = ops.make_conv_desc(B, shapes, shapes, cin, cout, k, 1, 1, 1, cin, cout, cout)
+    x = torch.as_tensor(rng.standard_normal((rows, cin)), dtype=torch.float32).cuda()
+    w = torch.as_tensor(rng.standard_normal((k * k * cin, cout)) * 0.05, dtype=torch.float32).cuda()
+    dy = torch.zeros((rows, cout), dtype=torch.float32, device="cuda")
+    live = torch.as_tensor(rng.uniform(size=rows) < frac).cuda()
+    dy[live] = torch.as_tensor(rng.standard_normal((int(live.sum()), cout)), dtype=torch.float32).cuda()
+    i16 = dict(dtype=torch.int16, device="cuda")
+    fh, fl = torch.zeros((k * k, cout, cin), **i16), torch.zeros((k * k, cout, cin), **i16)
+    dh, dl = torch.zeros((k * k, cin, cout), **i16), torch.zeros((k * k, cin, cout), **i16)
+    ops.conv_split_weights3(ctx, d, w, fh, fl, dh, dl)
+    flags, blocks = ops.row_block_list(ctx, dy, cout)
+    nb = (rows + 31) // 32
+    want = np.array([bool(live[32 * b: 32 * b + 32].any()) for b in range(nb)])
+    assert np.array_equal(flags.cpu().numpy().astype(bool), want)
+    bl = blocks.cpu().numpy()
+    assert bl[0] == want.sum() and np.array_equal(bl[1: 1 + bl[0]], np.nonzero(want)[0])
+    add = torch.as_tensor(rng.standard_normal((rows, cin)), dtype=torch.float32).cuda()
+    msk = torch.as_tensor(rng.standard_normal((rows, cin)), dtype=torch.float32).cuda()
+    dx0, dx1 = torch.full((rows, cin), float("nan"), device="cuda"), torch.full((rows, cin), float("nan"), device="cuda")
+    ops.conv_bwd_data3(ctx, d, dy, dh, dl, add, msk, dx0)
+    ops.conv_bwd_data3(ctx, d, dy, dh, dl, add, msk, dx1, dy_skip=(flags, blocks))
+    assert torch.equal(dx0, dx1)
+    dw0, dw1 = torch.zeros_like(w), torch.zeros_like(w)
+    db0, db1 = torch.zeros((cout,), device="cuda"), torch.zeros((cout,), device="cuda")
+    ops.conv_bwd_weight3(ctx, d, x, dy, dw0, db0)
+    ops.conv_bwd_weight3(ctx, d, x, dy, dw1, db1, dy_skip=(flags, blocks))
+    scale = max(float(dw0.abs().max()), 1e-30)
+    assert float((dw0 - dw1).abs().max()) <= 2e-6 * scale and float((db0 - db1).abs().max()) <= 2e-6 * max(float(db0.abs().max()), 1e-30)
+    if frac == 0.0:
+        assert not dw1.any() and not db1.any() and torch.equal(dx1, torch.where(msk > 0, add, torch.zeros_like(add)))
+    # the hint is one-shot: the next call is dense again
+    dw2 = torch.zeros_like(w)
+    ops.conv_bwd_weight3(ctx, d, x, dy, dw2, None)
+    assert float((dw0 - dw2).abs().max()) <= 2e-6 * scale

@@ -460,3 +460,34 @@ def test_pyramid_variants_vs_oracle_f64(ctx, pyramid, anchors):
 def ops_box3d(eng, reg):
     from pyrapose_amd import ops
     return ops.box3d_decode(eng.ctx, eng.anchors_device_f32(), torch.from_numpy(reg).cuda()).cpu().numpy()
+
+
+def test_sparse_backward_of_box_head_matches_dense(ctx, monkeypatch):
+    """PP_SPARSE_BWD (default: the 3D-box head): row-block lists + tile skipping leave losses, data gradients and weight
+    gradients of the whole graph unchanged (up to the float32 atomics of the split weight-gradient reductions)."""
+    from pyrapose_amd import arch
+    from pyrapose_amd.engine import Engine
+    B, H, W, C = 2, 128, 160, 6
+    rng = np.random.default_rng(31)
+    Wt = arch.init_weights(C, seed=32)
+    x = torch.from_numpy(synth_input(rng, B, H, W)).cuda()
+    got = {}
+    for mode in ("0", "reg"):
+        monkeypatch.setenv("PP_SPARSE_BWD", mode)
+        eng = Engine(ctx, C, B, H, W, weights=Wt, train=True, conv_mode="bf16x3")
+        if mode == "0":
+            tg = [torch.from_numpy(a).cuda() for a in random_targets(rng, B, eng.N, eng.M3, C, pos_frac=0.002)]
+        eng.set_targets(*tg)
+        eng.forward(x)
+        eng.loss_and_backward()
+        torch.cuda.synchronize()
+        lists = [o for o in eng.graph_ops if o.get("skip") is not None]
+        got[mode] = (eng.params.grad.clone(), eng.losses(), [o["spec"].name for o in lists],
+                     [(int(o["skip"][1][0]), int(o["skip"][0].numel())) for o in lists])
+    assert got["0"][2] == [] and sorted(got["reg"][2]) == ["reg_conv0", "reg_conv1", "reg_conv2", "reg_conv3", "reg_out"]
+    print("active / total 32-row blocks per layer:", dict(zip(got["reg"][2], got["reg"][3])))
+    assert all(0 < a < n for a, n in got["reg"][3])  # some blocks, not all
+    for k in ("3Dbox", "cls", "mask"):  # (the loss sums are float32 atomics: equal to rounding)
+        assert abs(got["0"][1][k] - got["reg"][1][k]) <= 1e-6 * abs(got["0"][1][k])
+    g0, g1 = got["0"][0].double(), got["reg"][0].double()
+    assert float((g0 - g1).norm() / g0.norm()) < 1e-6 and float((g0 - g1).abs().max() / g0.abs().max()) < 1e-5

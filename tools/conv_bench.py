@@ -93,8 +93,23 @@ def main():
         ops.split_planes3(ctx, dy, gh, gl)
         yh, yl = torch.zeros((rows, ld_w), **i16), torch.zeros((rows, ld_w), **i16)
         dxh, dxl = torch.zeros((rows_in, cin), **i16), torch.zeros((rows_in, cin), **i16)
+        # a sparse gradient like the 3D-box head's: non-zero in a few square patches per image of the first level
+        dys = torch.zeros_like(dy)
+        h0, w0 = out_shapes[0]
+        for n in range(B):
+            for _ in range(2):
+                cy, cx, r = int(torch.randint(0, h0, (1,))), int(torch.randint(0, w0, (1,))), int(os.environ.get("PP_PATCH", "8"))
+                for yy in range(max(0, cy - r), min(h0, cy + r)):
+                    a = (n * h0 + yy) * w0
+                    dys[a + max(0, cx - r): a + min(w0, cx + r)] = dy[a + max(0, cx - r): a + min(w0, cx + r)]
+        skip = ops.row_block_list(ctx, dys, cout)
         fns = {"fwd3pp": lambda: ops.conv_fwd3(ctx, d, None, fh, fl, bias, None, True, y, x_planes=(xh, xl), y_planes=(yh, yl)),
                "dgrad3pp": lambda: ops.conv_bwd_data3(ctx, d, None, dh, dl, None, x, dx, dy_planes=(gh, gl), dx_planes=(dxh, dxl)),
+               "dgrad3s": lambda: ops.conv_bwd_data3(ctx, d, dys, dh, dl, None, x, dx, dy_skip=skip),
+               "wgrad3s": lambda: ops.conv_bwd_weight3(ctx, d, x, dys, dw, db, dy_skip=skip),
+               "dgrad3d": lambda: ops.conv_bwd_data3(ctx, d, dys, dh, dl, None, x, dx),
+               "wgrad3d": lambda: ops.conv_bwd_weight3(ctx, d, x, dys, dw, db),
+               "rowlist": lambda: ops.row_block_list(ctx, dys, cout, skip[0], skip[1]),
                "fwd3c": lambda: ops.conv_fwd3(ctx, d, x, fh, fl, bias, None, True, y, x_capture=(xh, xl)),
                "dgrad3c": lambda: ops.conv_bwd_data3(ctx, d, dy, dh, dl, None, x, dx, dy_capture=(gh, gl)),
                "fwd3p": lambda: ops.conv_fwd3(ctx, d, None, fh, fl, bias, None, True, y, x_planes=(xh, xl)),
