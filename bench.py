@@ -138,22 +138,16 @@ def main():
 
     def sparse_fractions(eng):
         """Share of the reduction that the row-block skip of the 3D-box head's backward actually executes, per layer:
-        weight gradient = listed 32-row blocks / all blocks; data gradient = output tiles (126 rows of a 128-row tile, the
-        shape these launches take) that can reach a listed block / all tiles -- the rule of igemm3x_kernel."""
+        weight gradient = 32-row blocks of dy that hold a non-zero / all blocks; data gradient = 32-row blocks of dx that such
+        a block can reach (the second half of the flags buffer, written by the bwd-data launch) / all blocks."""
         out = {}
         for op in eng.graph_ops:
             sk = op.get("skip")
             if sk is None:
                 continue
-            flags = sk[0].cpu().numpy().astype(bool)
-            rows = op["y"].rows
-            halo = max(w for (_, w) in op["y"].shapes) + 1
-            tiles = (rows + 125) // 126
-            act = 0
-            for t in range(tiles):
-                lo, hi = max(t * 126 - 1 - halo, 0), min(t * 126 - 1 + 127 + halo, rows - 1)
-                act += bool(flags[lo >> 5: (hi >> 5) + 1].any())
-            out[op["spec"].name] = {"wgrad": float(flags.mean()), "dgrad": act / tiles}
+            nb = sk[0].numel() // 2
+            both = sk[0].cpu().numpy().astype(bool)
+            out[op["spec"].name] = {"wgrad": float(both[:nb].mean()), "dgrad": float(both[nb:].mean())}
         return out
 
     def run(mode, steps, warmup, events, dump_ops=None, sparse=None):

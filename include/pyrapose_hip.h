@@ -55,10 +55,12 @@ int pp_ctx_set_split_capture(pp_ctx* ctx, void* hi, void* lo);
  * state 1, so the gradient that flows back through the 3D-box head is exactly zero away from the positive anchors (and
  * stays so layer after layer, dilated by one pixel per 3x3 conv).  pp_row_block_list scans a gradient tensor x [rows][ld]
  * (first `cols` columns) once: flags[b] = 1 when the 32-row block b holds a non-zero (or a NaN), list = {count, the flagged
- * block indices ascending} (flags: ceil(rows/32) bytes, list: 1 + ceil(rows/32) ints, device memory).
+ * block indices ascending}.  With nb = ceil(rows/32): flags holds 2 nb bytes and list 2 (nb + 1) ints of device memory --
+ * the first halves are the result, the second halves scratch of the bwd-data launch that takes the hint.
  * pp_ctx_set_row_block_skip is one-shot: the NEXT pp_conv2d_nhwc_bwd_weight_bf16x3 call on this context (float32 operands)
- * reduces over the listed blocks of dy only, the NEXT pp_conv2d_nhwc_bwd_data_bf16x3 call (3x3, stride 1) skips the
- * reduction of output tiles none of whose reachable dy blocks is flagged (the epilogue still applies addend / mask).  A
+ * reduces over the listed blocks of dy only; the NEXT pp_conv2d_nhwc_bwd_data_bf16x3 call (3x3, stride 1, pad 1) computes
+ * only the 32-row blocks of dx that a flagged block of dy can reach (dilated by one pixel in 2-D, compacted four to a tile)
+ * and writes mask?(addend or 0) to the others.  A
  * block of zero rows contributes exactly 0.0 to every sum: the results are those of the dense launch (up to the order of
  * the float32 atomics between reduction splits).  Launches that cannot use the hint run dense.  NULL, NULL cancels. */
 int pp_row_block_list(pp_ctx* ctx, const float* x, int rows, int ld, int cols, unsigned char* flags, int* list);

@@ -60,11 +60,14 @@ __device__ __forceinline__ int div_small(int a, int b, float rcp_b, int* rem) {
 }
 
 // ---- epilogue through LDS (see conv.hip), shared by both main loops ----
-template <int TM, int TN, bool OP, int GOP = 1, bool SC = false, bool XR = false>
+// RL: the tile's BM rows are BM / 32 listed 32-row blocks (rl_blk[j] = first row of block j of this tile, >= M when the
+// list has ended) instead of the consecutive rows m0 ..
+template <int TM, int TN, bool OP, int GOP = 1, bool SC = false, bool XR = false, bool RL = false>
 __device__ __forceinline__ void epilogue3(const IgemmParams& p, floatx16 (&acc)[TM][TN], uint4* smem, int m0, int n0, int tid, int wm,
                                           int wn, int il, int h, const float* __restrict__ g_bias,
                                           const float* __restrict__ g_addend, const float* __restrict__ g_mask,
-                                          float* __restrict__ g_out, uint2* __restrict__ g_ohi, uint2* __restrict__ g_olo) {
+                                          float* __restrict__ g_out, uint2* __restrict__ g_ohi, uint2* __restrict__ g_olo,
+                                          const int* rl_blk = nullptr) {
   constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, NO = BK / 8;
   constexpr int SMEM_U4 = 2 * NO * (BM + BN);
   // blocked sub-tiles here, so staged row = (a - a0) * 32 + i
@@ -107,7 +110,11 @@ __device__ __forceinline__ void epilogue3(const IgemmParams& p, floatx16 (&acc)[
             int mo[G];  // row of the output / addend / mask tensors (SC: the class row scattered into the full grid)
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-              const int m = XR ? max(min(base_row + e_r + RPI * (s0 + g), m_last), 0) : min(base_row + e_r + RPI * (s0 + g), m_last);
+              int m = XR ? max(min(base_row + e_r + RPI * (s0 + g), m_last), 0) : min(base_row + e_r + RPI * (s0 + g), m_last);
+              if (RL) {
+                const int t = hm * 32 * TM + a0 * 32 + e_r + RPI * (s0 + g);
+                m = min(rl_blk[t >> 5] + (t & 31), m_last);
+              }
               mo[g] = m;
               if (SC) {
                 const int hw = p.seg[0].OH * p.seg[0].OW;
@@ -122,7 +129,11 @@ __device__ __forceinline__ void epilogue3(const IgemmParams& p, floatx16 (&acc)[
 #pragma unroll
             for (int g = 0; g < G; ++g) {
               const int row = e_r + RPI * (s0 + g);
-              const int m = base_row + row;
+              int m = base_row + row;
+              if (RL) {
+                const int t = hm * 32 * TM + a0 * 32 + row;
+                m = rl_blk[t >> 5] + (t & 31);
+              }
               float4 v = *reinterpret_cast<const float4*>(stage + row * BN + 4 * e_c4);
               v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
               if (has_add) { v.x += ad[g].x; v.y += ad[g].y; v.z += ad[g].z; v.w += ad[g].w; }
@@ -356,13 +367,17 @@ __device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, const uint
 // 3x3 gather re-reads its activation rows nine times, so keeping THEM in L2 matters more than the weights.
 // Measured and NOT kept: the same loop on v_mfma_f32_16x16x32_bf16 (48 instead of 24 MFMAs per step, lane = (row, octet)
 // staging map, un-rotated image): bit-identical results, 20 % slower on every head shape (255-295 vs 325-355 TFLOP/s).
-template <int TM, int TN, bool AP, bool OP, bool SC = false>
+// RL (row list): the launch computes only the 32-row output blocks of a list (g_rl[0] = count, g_rl[1 ..] ascending block
+// indices; pp_ctx_set_row_block_skip: the blocks of the data gradient that a non-zero of dy can reach), four (two) blocks
+// to a tile; the grid is sized for the dense case and workgroups past the end of the list leave at once.  Rows keep their
+// own gather offsets (this loop never assumed that the rows of a tile are consecutive); rl_fill_kernel writes the rest.
+template <int TM, int TN, bool AP, bool OP, bool SC = false, bool RL = false>
 __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4)) void igemm3f_kernel(
     const IgemmParams p, const void* __restrict__ g_a0, const void* __restrict__ g_a1, unsigned a_bytes,
     const void* __restrict__ g_whi, const void* __restrict__ g_wlo, unsigned w_bytes,
     const float* __restrict__ g_bias, const float* __restrict__ g_addend, const float* __restrict__ g_mask,
     float* __restrict__ g_out, uint2* __restrict__ g_ohi, uint2* __restrict__ g_olo, int w_rows, int w_ld8, int splits,
-    float* __restrict__ g_ws) {
+    float* __restrict__ g_ws, const int* __restrict__ g_rl = nullptr) {
   constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, NO = BK / 8;
   constexpr int SMEM_U4 = 2 * NO * (BM + BN);
   constexpr int ES = AP ? 2 : 4;  // bytes per gathered element
@@ -374,10 +389,25 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int lbs = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  int n_wg = (int)gridDim.x;
+  if (RL) {  // the grid is sized for the dense case: only the first ceil(count / blocks per tile) x n_tiles_n workgroups work,
+             // and the XCD remap runs over THEM (over the whole grid the listed tiles would all land on the first XCDs)
+    n_wg = ((g_rl[0] + BM / 32 - 1) / (BM / 32)) * p.n_tiles_n;
+    if ((int)blockIdx.x >= n_wg) return;  // workgroup-uniform, before any barrier
+  }
+  const int lbs = xcd_remap((int)blockIdx.x, n_wg);
   const int split = lbs % splits, lb = lbs / splits;  // split-K: `splits` workgroups share one output tile
   const int tile_n = lb % p.n_tiles_n, tile_m = lb / p.n_tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  int rl_blk[BM / 32];  // RL: first row of each listed block of this tile
+  if (RL) {
+    const int count = g_rl[0];
+#pragma unroll
+    for (int j = 0; j < BM / 32; ++j) {
+      const int e = tile_m * (BM / 32) + j;
+      rl_blk[j] = e < count ? g_rl[1 + e] * 32 : ((p.M + 31) & ~31);
+    }
+  }
   const int oct = tid & 3, r0 = tid >> 2;
   const int n_taps = p.kh * p.kw;
   const int steps_per_tap = p.Cred / BK;
@@ -394,7 +424,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
   unsigned a_valid[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const RowPos r = decode_row(p, m0 + r0 + 64 * i);
+    const int t_row = r0 + 64 * i;
+    const RowPos r = decode_row(p, RL ? rl_blk[t_row >> 5] + (t_row & 31) : m0 + t_row);
     a_base[i] = ((r.rowbase + r.ybase * r.SW + r.xbase) * p.ld_src + 8 * oct) * ES;
     a_pitch[i] = p.tsign * r.SW * p.ld_src * ES;
     unsigned v = 0;
@@ -550,7 +581,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
       }
     return;
   }
-  epilogue3<TM, TN, OP, 4, SC>(p, acc, smem, m0, n0, tid, wm, wn, il, h, g_bias, g_addend, g_mask, g_out, g_ohi, g_olo);
+  epilogue3<TM, TN, OP, 4, SC, false, RL>(p, acc, smem, m0, n0, tid, wm, wn, il, h, g_bias, g_addend, g_mask, g_out, g_ohi, g_olo, rl_blk);
 }
 
 // ---- igemm3x: 3-wide stride-1 "same" convolutions with the gathered tile shared by the three taps of a kernel row ----
@@ -1051,6 +1082,70 @@ static bool igemm3_fast_ok(const IgemmParams& p, bool planes, int w_rows, int w_
          (long long)max_sw * p.ld_src * 4 < (1ll << 23) && p.src_rows > 0;
 }
 
+// ---- sparse data gradient of a 3x3 stride-1 conv: which 32-row OUTPUT blocks can a non-zero of dy reach? ----
+// Output row m reads dy rows m + dy * W + dx, dy, dx in {-1, 0, 1} (W = width of m's level): block b is live when a flagged
+// dy block intersects one of the three 34-row windows [32 b - 1 + j W, 32 b + 32 + j W], j = -1, 0, 1 -- exact in 2-D up to
+// the 32-cell granularity (image / level boundaries are ignored: conservative).
+__global__ void rl_dilate_kernel(const IgemmParams p, const unsigned char* __restrict__ in_flags, unsigned char* __restrict__ out_flags,
+                                 int n_blocks) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_blocks) return;
+  const int r_lo = 32 * b, r_hi = min(32 * b + 31, p.M - 1);
+  int any = 0;
+  for (int s = 0; s < p.n_seg; ++s) {
+    const int seg_lo = p.seg[s].row_begin, seg_hi = (s + 1 < p.n_seg ? p.seg[s + 1].row_begin : p.M) - 1;
+    if (r_hi < seg_lo || r_lo > seg_hi) continue;
+    const int W = p.seg[s].OW;
+    for (int j = -1; j <= 1; ++j) {
+      int lo = r_lo - 1 + j * W, hi = r_hi + 1 + j * W;
+      lo = lo < 0 ? 0 : lo;
+      hi = hi > p.M - 1 ? p.M - 1 : hi;
+      for (int q = lo >> 5; q <= (hi >> 5); ++q) any |= in_flags[q];
+    }
+  }
+  out_flags[b] = any ? 1 : 0;
+}
+
+// rows of the blocks that no non-zero reaches: dx = mask?(addend or 0)
+__global__ void rl_fill_kernel(const IgemmParams p, const unsigned char* __restrict__ live, const float* __restrict__ g_addend,
+                               const float* __restrict__ g_mask, float* __restrict__ g_out) {
+  const int b = blockIdx.x;
+  if (live[b]) return;
+  const int n4 = (p.Nout + 3) >> 2;
+  const int r0 = 32 * b, nr = min(32, p.M - r0);
+  for (int i = threadIdx.x; i < nr * n4; i += blockDim.x) {
+    const int r = i / n4, co = 4 * (i - r * n4);
+    const long long m = r0 + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g_addend) v = *reinterpret_cast<const float4*>(g_addend + m * p.ld_add + co);
+    if (g_mask) {
+      const float4 k = *reinterpret_cast<const float4*>(g_mask + m * p.ld_mask + co);
+      v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+    }
+    *reinterpret_cast<float4*>(g_out + m * p.ld_out + co) = v;
+  }
+}
+
+__global__ void row_block_compact_kernel(const unsigned char* __restrict__ flags, int n_blocks, int* __restrict__ list);
+
+// the whole sparse bwd-data: dilate -> compact -> igemm3f over the listed blocks -> fill the others.  scratch: n_blocks bytes
+// + (n_blocks + 1) ints behind the caller's flags / list (pp_row_block_list documents the sizes).
+template <int TM, int TN>
+static void launch_igemm3_rowlist(hipStream_t st, IgemmParams& p, const void* whi, const void* wlo, int w_rows, int w_ld8,
+                                  const unsigned char* dy_flags, unsigned char* out_flags, int* out_list) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  const int nb = (p.M + 31) / 32;
+  hipLaunchKernelGGL(rl_dilate_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, p, dy_flags, out_flags, nb);
+  hipLaunchKernelGGL(row_block_compact_kernel, dim3(1), dim3(256), 0, st, (const unsigned char*)out_flags, nb, out_list);
+  p.n_tiles_n = (p.Nout + BN - 1) / BN;
+  const int n_tiles_m = (nb + BM / 32 - 1) / (BM / 32);
+  const long long a_bytes = p.src_rows * (long long)p.ld_src * 4, w_bytes = (long long)p.w_taps * w_rows * w_ld8 * 16;
+  hipLaunchKernelGGL((igemm3f_kernel<TM, TN, false, false, false, true>), dim3((unsigned)(n_tiles_m * p.n_tiles_n)), dim3(256), 0, st, p,
+                     (const void*)p.src, nullptr, (unsigned)a_bytes, whi, wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out,
+                     (uint2*)nullptr, (uint2*)nullptr, w_rows, w_ld8, 1, (float*)nullptr, (const int*)out_list);
+  hipLaunchKernelGGL(rl_fill_kernel, dim3((unsigned)nb), dim3(256), 0, st, p, (const unsigned char*)out_flags, p.addend, p.mask_src, p.out);
+}
+
 static void split_capture_pass(hipStream_t st, const IgemmParams& p, void* chi, void* clo) {
   const size_t n8 = (size_t)(p.src_rows * (long long)p.ld_src / 8);
   size_t blocks = (n8 + 255) / 256;
@@ -1261,6 +1356,8 @@ extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d
   void *chi = ctx->cap_hi, *clo = ctx->cap_lo;  // one-shot (pp_ctx_set_split_capture)
   ctx->cap_hi = ctx->cap_lo = nullptr;
   const unsigned char* skip_flags = ctx->skip_flags;  // one-shot (pp_ctx_set_row_block_skip)
+  const int* skip_list_in = ctx->skip_list;
+  const bool skip_scratch_ok = skip_flags != nullptr && skip_list_in != nullptr;
   ctx->skip_flags = nullptr;
   ctx->skip_list = nullptr;
   int rc = check_desc(ctx, d, "pp_conv2d_nhwc_bwd_data_bf16x3");
@@ -1331,6 +1428,24 @@ extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d
           hipLaunchKernelGGL(class_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, cls[c], addend, relu_src, dx);
         }
       }
+      PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_data_bf16x3");
+      return PP_OK;
+    }
+  }
+  if (skip_flags && skip_scratch_ok && !dy_hi && !dx_hi && dy && dx && !chi && d->stride == 1 && d->kh == 3 && d->kw == 3 && d->pad_t == 1 &&
+      d->pad_l == 1 && p.bias == nullptr && igemm3_fast_ok(p, false, d->cin, cred / 8)) {
+    bool same = true;
+    for (int i = 0; i < p.n_seg && same; ++i)
+      same = p.seg[i].OH == p.seg[i].SH && p.seg[i].OW == p.seg[i].SW && p.seg[i].row_begin == p.seg[i].src_row_begin;
+    // PP_SPARSE_DGRAD: 22 (default) / 12 = tile of the listed-block launch (equal within noise on the bench step), 0 = keep
+    // the dense grid and skip the k-loop of tiles that see no flagged block (coarser: a 126-row tile spans 1.6 image rows)
+    static const int rl_mode = []() { const char* e = getenv("PP_SPARSE_DGRAD"); return e ? atoi(e) : 22; }();
+    if (same && rl_mode) {
+      const int nb = (p.M + 31) / 32;
+      unsigned char* out_flags = const_cast<unsigned char*>(skip_flags) + nb;
+      int* out_list = const_cast<int*>(skip_list_in) + nb + 1;
+      if (rl_mode == 22) launch_igemm3_rowlist<2, 2>(ctx->stream, p, w_hi, w_lo, d->cin, cred / 8, skip_flags, out_flags, out_list);
+      else launch_igemm3_rowlist<1, 2>(ctx->stream, p, w_hi, w_lo, d->cin, cred / 8, skip_flags, out_flags, out_list);
       PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_data_bf16x3");
       return PP_OK;
     }

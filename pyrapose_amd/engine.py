@@ -694,8 +694,8 @@ class Engine(object):
                 s, x = op["spec"], op["x"]
                 if self._sparse_layer(s) and g.pl is None and g.t.is_contiguous() and g.t.dim() == 2:
                     nb = (g.t.shape[0] + 31) // 32
-                    skip = op["skip"] = (torch.zeros((nb,), dtype=torch.uint8, device="cuda"),
-                                         torch.zeros((nb + 1,), dtype=torch.int32, device="cuda"))
+                    skip = op["skip"] = (torch.zeros((2 * nb,), dtype=torch.uint8, device="cuda"),   # flags | bwd-data scratch
+                                         torch.zeros((2 * (nb + 1),), dtype=torch.int32, device="cuda"))
                     cols = min((y.C + 3) // 4 * 4, g.t.shape[1])
                     self.bwd_ops.append(Op(lambda gt=g.t, cols=cols, skip=skip: ops.row_block_list(ctx, gt, cols, skip[0], skip[1]),
                                            "pointwise", "rowblocks:" + s.name))

@@ -122,13 +122,14 @@ def _set_capture(ctx, planes):
 
 
 def row_block_list(ctx, x, cols, flags=None, blocks=None):
-    """pp_row_block_list: x float32 [rows, ld] -> (flags uint8 [nb], list int32 [1 + nb]) with nb = ceil(rows / 32)."""
+    """pp_row_block_list: x float32 [rows, ld] -> (flags uint8 [2 nb], list int32 [2 (1 + nb)]) with nb = ceil(rows / 32);
+    the first halves hold the result, the second halves are scratch of the bwd-data launch that takes the hint."""
     rows, ld = x.shape
     nb = (rows + 31) // 32
     if flags is None:
-        flags = torch.empty((nb,), dtype=torch.uint8, device=x.device)
+        flags = torch.zeros((2 * nb,), dtype=torch.uint8, device=x.device)
     if blocks is None:
-        blocks = torch.empty((nb + 1,), dtype=torch.int32, device=x.device)
+        blocks = torch.zeros((2 * (nb + 1),), dtype=torch.int32, device=x.device)
     check(lib.pp_row_block_list(ctx.handle, _ptr(x), rows, x.stride(0), int(cols), _ptr(flags), _ptr(blocks)), ctx.handle, "pp_row_block_list")
     return flags, blocks
 

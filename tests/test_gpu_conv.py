@@ -494,7 +494,7 @@ def test_row_block_skip_matches_dense(ctx, frac):
     flags, blocks = ops.row_block_list(ctx, dy, cout)
     nb = (rows + 31) // 32
     want = np.array([bool(live[32 * b: 32 * b + 32].any()) for b in range(nb)])
-    assert np.array_equal(flags.cpu().numpy().astype(bool), want)
+    assert np.array_equal(flags.cpu().numpy()[:nb].astype(bool), want)
     bl = blocks.cpu().numpy()
     assert bl[0] == want.sum() and np.array_equal(bl[1: 1 + bl[0]], np.nonzero(want)[0])
     add = torch.as_tensor(rng.standard_normal((rows, cin)), dtype=torch.float32).cuda()
@@ -502,7 +502,12 @@ def test_row_block_skip_matches_dense(ctx, frac):
     dx0, dx1 = torch.full((rows, cin), float("nan"), device="cuda"), torch.full((rows, cin), float("nan"), device="cuda")
     ops.conv_bwd_data3(ctx, d, dy, dh, dl, add, msk, dx0)
     ops.conv_bwd_data3(ctx, d, dy, dh, dl, add, msk, dx1, dy_skip=(flags, blocks))
-    assert torch.equal(dx0, dx1)
+    assert rel_err(dx1.cpu().numpy(), dx0.cpu().numpy()) < 2e-6  # (another kernel: equal up to f32 summation order)
+    dead = ~flags[nb: 2 * nb].bool().cpu().numpy()  # scratch half: the dx blocks no non-zero reaches
+    if dead.any():
+        rows_dead = np.repeat(dead, 32)[:rows]
+        assert torch.equal(dx1[torch.as_tensor(rows_dead).cuda()], torch.where(msk > 0, add, torch.zeros_like(add))[torch.as_tensor(rows_dead).cuda()])
+    assert frac > 0.5 or dead.any()
     dw0, dw1 = torch.zeros_like(w), torch.zeros_like(w)
     db0, db1 = torch.zeros((cout,), device="cuda"), torch.zeros((cout,), device="cuda")
     ops.conv_bwd_weight3(ctx, d, x, dy, dw0, db0)
