@@ -62,7 +62,8 @@ int pp_ctx_set_split_capture(pp_ctx* ctx, void* hi, void* lo);
  * only the 32-row blocks of dx that a flagged block of dy can reach (dilated by one pixel in 2-D, compacted four to a tile)
  * and writes mask?(addend or 0) to the others.  A
  * block of zero rows contributes exactly 0.0 to every sum: the results are those of the dense launch (up to the order of
- * the float32 atomics between reduction splits).  Launches that cannot use the hint run dense.  NULL, NULL cancels. */
+ * the float32 atomics between reduction splits; the one exception is an Inf / NaN operand opposite an exact zero, which the
+ * dense launch turns into NaN and this one into 0).  Launches that cannot use the hint run dense.  NULL, NULL cancels. */
 int pp_row_block_list(pp_ctx* ctx, const float* x, int rows, int ld, int cols, unsigned char* flags, int* list);
 int pp_ctx_set_row_block_skip(pp_ctx* ctx, const unsigned char* flags, const int* list);
 const char* pp_last_error_string(pp_ctx* ctx);
