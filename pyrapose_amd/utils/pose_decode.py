@@ -30,21 +30,28 @@ def poses_from_outputs(boxes3D, scores, threeD_boxes, K, threshold=0.5, min_vote
     if Ks is None:
         raise ValueError("K must be 3x3 or [B,3,3]")
     idx, cnt = ops.score_threshold_compact(ctx, scores, float(threshold))  # bit-exact np.where order
-    cnt_h = cnt.cpu().numpy()
-    sel = [(b, c) for b in range(B) for c in range(C) if cnt_h[b, c] >= max(int(min_votes), 1)]
-    if not sel:
+    # everything below stays on the device until the poses come back: one gather for all (image, class) problems
+    sel = cnt >= max(int(min_votes), 1)                                        # [B, C]
+    if not bool(sel.any()):
         return []
-    offs, objs, imgs, K4, votes = [0], [], [], [], []
-    for b, c in sel:
-        k = int(cnt_h[b, c])
-        v = idx[b, c, :k].long()
-        votes.append(v)
-        imgs.append(boxes3D[b, v, :].double().reshape(k * 8, 2))
-        objs.append(corners[c].repeat(k, 1))
-        K4.append([Ks[b][0, 0], Ks[b][1, 1], Ks[b][0, 2], Ks[b][1, 2]])
-        offs.append(offs[-1] + 8 * k)
-    R, t, n_in, mask, ok = ops.pnp_ransac(ctx, torch.tensor(offs, dtype=torch.int32, device="cuda"), torch.cat(objs), torch.cat(imgs),
-                                          torch.tensor(K4, dtype=torch.float64, device="cuda"), iterations, reproj_error, seed, 8)
+    cap = idx.shape[2]
+    live = (torch.arange(cap, device="cuda")[None, None, :] < cnt[:, :, None]) & sel[:, :, None]  # [B, C, cap], (b, c, vote) order
+    b_of, c_of, _ = torch.nonzero(live, as_tuple=True)
+    anchor = idx[live].long()
+    img = boxes3D[b_of, anchor, :].double().reshape(-1, 2)
+    obj = corners[c_of].reshape(-1, 3)
+    k = cnt[sel].long()                                                        # votes per problem, (b, c) order
+    offs = torch.zeros((k.numel() + 1,), dtype=torch.int32, device="cuda")
+    offs[1:] = (8 * torch.cumsum(k, 0)).to(torch.int32)
+    pb, pc = torch.nonzero(sel, as_tuple=True)
+    K_all = torch.as_tensor(np.stack([[Kb[0, 0], Kb[1, 1], Kb[0, 2], Kb[1, 2]] for Kb in Ks]), dtype=torch.float64, device="cuda")
+    R, t, n_in, mask, ok = ops.pnp_ransac(ctx, offs, obj.contiguous(), img.contiguous(), K_all[pb].contiguous(), iterations, reproj_error, seed, 8)
     R, t, mask, ok = R.cpu().numpy(), t.cpu().numpy(), mask.cpu().numpy(), ok.cpu().numpy()
-    return [dict(image=b, cls=c, votes=votes[p].cpu().numpy(), ok=bool(ok[p]), R=R[p], t=t[p],
-                 inliers=np.nonzero(mask[offs[p]:offs[p + 1]])[0]) for p, (b, c) in enumerate(sel)]
+    offs_h, anchor_h, k_h = offs.cpu().numpy(), anchor.cpu().numpy(), k.cpu().numpy()
+    pb, pc = pb.cpu().numpy(), pc.cpu().numpy()
+    out, v0 = [], 0
+    for p in range(len(k_h)):
+        out.append(dict(image=int(pb[p]), cls=int(pc[p]), votes=anchor_h[v0: v0 + k_h[p]], ok=bool(ok[p]), R=R[p], t=t[p],
+                        inliers=np.nonzero(mask[offs_h[p]:offs_h[p + 1]])[0]))
+        v0 += int(k_h[p])
+    return out

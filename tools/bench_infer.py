@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--nms", action="store_true", help="also run filter_detections (D4) per image")
+    ap.add_argument("--pnp", action="store_true", help="also run the pose tail: per-class votes -> batched RANSAC-PnP (f2)")
     args = ap.parse_args()
     B, C, H, W = args.batch, args.classes, 480, 640
     ctx = ops.Context(0)
@@ -43,8 +44,14 @@ def main():
             xs, ys = boxes3d[..., 0::2], boxes3d[..., 1::2]
             boxes = torch.stack([xs.amin(-1), ys.amin(-1), xs.amax(-1), ys.amax(-1)], -1).contiguous()
             ops.filter_detections_batch(ctx, boxes, boxes3d, scores, 0.05, 0.5, 300)
+        if args.pnp:
+            poses[0] = pose_decode.poses_from_outputs(boxes3d, scores, corners, Kmat, threshold=0.5, min_votes=10, ctx=ctx)
         return scores, idx
 
+    from pyrapose_amd.utils import pose_decode
+    poses = [None]
+    corners = np.stack([np.array([[sx * 40.0, sy * 30.0, sz * 55.0] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])] * C)
+    Kmat = np.array([[572.4114, 0, 325.2611], [0, 573.57043, 242.04899], [0, 0, 1.0]])
     for _ in range(args.warmup):
         scores, idx = step()
     torch.cuda.synchronize()
@@ -57,9 +64,11 @@ def main():
     ms = e0.elapsed_time(e1) / args.steps
     frac = float((scores > 0.5).float().mean())
     N = anchors.shape[0]
-    print(json.dumps({"metric": "images/sec 640x480 inference (forward + anchors + box3D decode + score>0.5 compaction%s)" % (" + NMS" if args.nms else ""),
+    print(json.dumps({"metric": "images/sec 640x480 inference (forward + anchors + box3D decode + score>0.5 compaction%s)" % ((" + NMS" if args.nms else "") + (" + per-class RANSAC-PnP" if args.pnp else "")),
                       "value": B * 1e3 / ms, "unit": "images/sec", "anchors_per_sec": B * N * 1e3 / ms, "ms_per_batch": ms, "n_gpus": 1,
                       "dtype": eng.conv_mode, "data": "synthetic", "frac_scores_over_0.5": frac,
+                      "pnp_problems_per_batch": (len(poses[0]) if poses[0] is not None else None),
+                      "pnp_votes_per_batch": (int(sum(len(o["votes"]) for o in poses[0])) if poses[0] is not None else None),
                       "config": {"workload": "Occlusion-style inference, batch %d, %d classes, 640x480 (SURVEY 8d config 3)" % (B, C)}}))
 
 
