@@ -1117,10 +1117,12 @@ __global__ void rl_fill_kernel(const IgemmParams p, const unsigned char* __restr
     const int r = i / n4, co = 4 * (i - r * n4);
     const long long m = r0 + r;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g_addend) v = *reinterpret_cast<const float4*>(g_addend + m * p.ld_add + co);
-    if (g_mask) {
-      const float4 k = *reinterpret_cast<const float4*>(g_mask + m * p.ld_mask + co);
-      v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+    if (g_addend) {  // (without an addend the row is zero whatever the mask says: nothing to read)
+      v = *reinterpret_cast<const float4*>(g_addend + m * p.ld_add + co);
+      if (g_mask) {
+        const float4 k = *reinterpret_cast<const float4*>(g_mask + m * p.ld_mask + co);
+        v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+      }
     }
     *reinterpret_cast<float4*>(g_out + m * p.ld_out + co) = v;
   }
