@@ -48,7 +48,7 @@ def measured_peak(mode, achieved):
             "mfma_issue_frac_of_measured": achieved * 3 / m, "source": "profiles/r01_peaks.json (tools/ubench/peaks.hip, 20 ms launches)"}
 
 
-def synth_batch(B, H, W, C, seed):
+def synth_batch(B, H, W, C, seed, side=(40, 160)):
     """images uint8 U[0,255] - caffe means; K~U{1..3} boxes, sides U[40,160]."""
     rng = np.random.default_rng(seed)
     x = rng.integers(0, 256, size=(B, H, W, 3)).astype(np.float32) - np.array([103.939, 116.779, 123.68], np.float32)
@@ -60,7 +60,7 @@ def synth_batch(B, H, W, C, seed):
         a = {"mask": [mask], "labels": np.empty((0,)), "bboxes": np.empty((0, 4)), "poses": np.empty((0, 7)),
              "segmentations": np.empty((0, 8, 3)), "cam_params": np.empty((0, 4)), "mask_ids": np.empty((0,))}
         for k in range(K):
-            w, h = rng.uniform(40, 160, 2)
+            w, h = rng.uniform(side[0], side[1], 2)
             x1, y1 = rng.uniform(0, W - w), rng.uniform(0, H - h)
             mask[int(y1):int(y1 + h), int(x1):int(x1 + w)] = k + 1
             z = 800.0

@@ -886,6 +886,25 @@ class Engine(object):
             self.grad_sync.finish()
         self.optimizer_step()
 
+    def train_step_from_annotations(self, images_u8, annotations, image_group=None):
+        """The lean feed of one optimisation step: a uint8 BGR batch [B,H,W,3] (cuda, or pinned host memory) and the raw
+        annotation dicts of preprocessing/generator.py:142-226 (bboxes, labels, poses, segmentations, cam_params, mask,
+        mask_ids).  Mean subtraction + packing (image.py:58-60, generator.py:320-336) and target assignment
+        (utils/anchors.py:72-287) run on the device: 7.4 MB cross PCIe per batch of 8 instead of 87.9 MB."""
+        from .utils import anchors as UA
+        if getattr(self, "_anchors_f64", None) is None:
+            self._anchors_f64 = UA.anchors_for_shape_device((self.H, self.W), pyramid_levels=list(arch.PYRAMID_LEVELS[self.pyramid]),
+                                                            anchor_params=self.anchor_params)
+        xd = images_u8 if images_u8.is_cuda else images_u8.cuda(non_blocking=True)
+        if image_group is None:
+            image_group = [np.empty((self.H, self.W, 3), np.uint8)] * self.B  # only the shapes are read
+        self.set_targets(*UA.anchor_targets_bbox_device(self._anchors_f64, image_group, annotations, self.C))
+        self.forward_u8(xd, [(int(im.shape[0]), int(im.shape[1])) for im in image_group])
+        self.loss_and_backward()
+        if self.grad_sync is not None:
+            self.grad_sync.finish()
+        self.optimizer_step()
+
     def losses(self):
         v = self.loss_sums.detach().cpu().numpy()
         return {"3Dbox": float(v[0]), "cls": float(v[1]), "mask": float(v[2]), "l2": float(v[3]), "total": float(v.sum())}

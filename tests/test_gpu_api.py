@@ -198,3 +198,34 @@ def test_fit_generator_prefetch_matches_synchronous_loop():
     assert np.allclose(l0, l1, rtol=1e-5, atol=1e-6), (l0, l1)
     for k in w0:
         assert np.abs(w0[k] - w1[k]).max() <= 1e-6 * max(np.abs(w0[k]).max(), 1e-3), k
+
+
+def test_train_step_from_annotations_equals_the_numpy_feed():
+    """Engine.train_step_from_annotations (uint8 images + raw annotations, preprocessing and target assignment on the device)
+    takes the same step as the reference-shaped feed: preprocess_image + compute_inputs on the host, anchor_targets_bbox."""
+    import numpy as np
+    import torch
+    import bench
+    from pyrapose_amd import arch
+    from pyrapose_amd.engine import Engine
+    from pyrapose_amd.runtime import default_context
+    from pyrapose_amd.utils import anchors as UA
+    B, H, W, C = 2, 128, 160, 5
+    rng = np.random.default_rng(41)
+    _, images, anns = bench.synth_batch(B, H, W, C, seed=42, side=(24, 64))
+    u8 = rng.integers(0, 256, (B, H, W, 3)).astype(np.uint8)
+    Wt = arch.init_weights(C, seed=43)
+    ctx = default_context()
+    # reference-shaped feed: float32 BGR minus caffe means (utils/image.py:58-60), numpy targets
+    x = u8.astype(np.float32) - np.array([103.939, 116.779, 123.68], np.float32)
+    anchors = UA.anchors_for_shape((H, W))
+    tg = UA.anchor_targets_bbox(anchors, [np.zeros((H, W, 3), np.uint8)] * B, anns, C)
+    e0 = Engine(ctx, C, B, H, W, weights=Wt, train=True)
+    e0.train_step(torch.from_numpy(x).cuda(), [torch.from_numpy(t).cuda() for t in tg])
+    e1 = Engine(ctx, C, B, H, W, weights=Wt, train=True)
+    e1.train_step_from_annotations(torch.from_numpy(u8).pin_memory(), anns)
+    l0, l1 = e0.losses(), e1.losses()
+    for k in l0:
+        assert abs(l0[k] - l1[k]) <= 1e-6 * max(abs(l0[k]), 1e-6), (k, l0[k], l1[k])
+    w0, w1 = e0.params.w_master, e1.params.w_master
+    assert float((w0 - w1).abs().max()) <= 1e-7 * float(w0.abs().max()) + 1e-9
