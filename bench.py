@@ -281,7 +281,7 @@ def main():
         else:
             peak, kname = PEAK_F32_MFMA_TFLOPS, "conv implicit-GEMM family (igemm fwd/bwd-data + wgrad): v_mfma_f32_32x32x2_f32"
         roofline = {"bound": "mfma", "achieved": roof["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": roof["achieved"] / peak,
-                    "traffic": traffic, "kernel": kname,
+                    "traffic": (traffic or {}).get("hbm_bytes_per_launch"), "traffic_detail": traffic, "kernel": kname,
                     "method": "sum of ALGORITHMIC 2*MAC flops of every conv launch / union of their HIP-event intervals, on every %d-th step of "
                               "the timed region (%d of %d steps; per-launch events on every step cost ~2.5 %% of the step time). "
                               "executed_tflops / frac_executed credit the backward launches of the 3D-box head, which skip the zero blocks of "
