@@ -311,7 +311,7 @@ def test_two_rank_data_parallel_equals_global_batch(ctx, tmp_path):
     torch.cuda.synchronize()
     g_ref, w_ref, counts_ref = eng.params.grad.cpu().numpy(), eng.params.w_master.cpu().numpy(), eng.counts.cpu().numpy()
     l_ref = np.array([eng.losses()[k] for k in ("3Dbox", "cls", "mask")])
-    env = dict(os.environ, GPU_MAX_HW_QUEUES="2", HSA_ENABLE_IPC_MODE_LEGACY="0")  # two ranks on one card (DESIGN.md 5.1)
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="2", HSA_ENABLE_IPC_MODE_LEGACY="0")  # two ranks on one card (DESIGN.md 6b)
     worker = os.path.join(os.path.dirname(__file__), "dp_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(r), "2", "29541", str(tmp_path)], env=env, stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]
