@@ -492,3 +492,36 @@ def test_sparse_backward_of_box_head_matches_dense(ctx, monkeypatch):
     g0, g1 = got["0"][0].double(), got["reg"][0].double()
     # (the listed-block data gradient is another kernel than the dense one: float32 summation order, a few 1e-6 after 5 layers)
     assert float((g0 - g1).norm() / g0.norm()) < 2e-5 and float((g0 - g1).abs().max() / g0.abs().max()) < 1e-4
+
+
+def test_sparse_backward_full_size_bench_config(ctx, monkeypatch):
+    """The bench configuration itself (batch 8, 640x480, 13 classes, targets from the synthetic annotations of SURVEY 8d
+    config 2 through the device target assignment): sparse and dense backward give the same losses and gradients, and
+    the support of the 3D-box gradient is what makes the difference (a fifth of the row blocks or less)."""
+    import bench
+    from pyrapose_amd import arch
+    from pyrapose_amd.engine import Engine
+    from pyrapose_amd.utils import anchors as UA
+    B, H, W, C = 8, 480, 640, 13
+    x, images, anns = bench.synth_batch(B, H, W, C, seed=1000)
+    anchors = UA.anchors_for_shape_device((H, W))
+    tg = UA.anchor_targets_bbox_device(anchors, images, anns, C)
+    Wt = arch.init_weights(C, seed=0)
+    xd = torch.from_numpy(x).cuda()
+    got = {}
+    for mode in ("0", "reg"):
+        monkeypatch.setenv("PP_SPARSE_BWD", mode)
+        eng = Engine(ctx, C, B, H, W, weights=Wt, train=True)
+        eng.set_targets(*tg)
+        eng.forward(xd)
+        eng.loss_and_backward()
+        torch.cuda.synchronize()
+        shares = [float(o["skip"][0][: o["skip"][0].numel() // 2].float().mean()) for o in eng.graph_ops if o.get("skip") is not None]
+        got[mode] = (eng.params.grad.clone(), eng.losses(), shares)
+        del eng
+        torch.cuda.empty_cache()
+    assert got["0"][2] == [] and len(got["reg"][2]) == 5 and 0 < max(got["reg"][2]) < 0.25
+    for k in ("3Dbox", "cls", "mask"):
+        assert abs(got["0"][1][k] - got["reg"][1][k]) <= 1e-6 * abs(got["0"][1][k])
+    g0, g1 = got["0"][0].double(), got["reg"][0].double()
+    assert float((g0 - g1).norm() / g0.norm()) < 2e-5 and float((g0 - g1).abs().max() / g0.abs().max()) < 1e-4
