@@ -1,0 +1,96 @@
+"""The callbacks bin/train.py:107-155 (create_callbacks) hands to fit_generator, with the Keras / reference names:
+ModelCheckpoint (keras.callbacks.ModelCheckpoint as configured there: one file per epoch, '{backbone}_{dataset}_{epoch:02d}.h5'),
+RedirectModel (callbacks/common.py:4-47) and ReduceLROnPlateau (monitor='loss', factor 0.1, patience 2).
+
+Checkpoint files keep whatever name the caller formats (the reference uses '.h5') but hold the numpy container of
+PyraPoseModel.save_weights (keys '<layer>/kernel' in Keras HWIO layout, '<layer>/bias', '<bn>/gamma|beta|moving_*'):
+h5py is not available to this image; load_weights recognises the container by its magic bytes, not by the extension."""
+from .models.model import ReduceLROnPlateau  # noqa: F401  (re-export under the callbacks namespace)
+
+
+class Callback(object):
+    """keras.callbacks.Callback surface used by the reference."""
+
+    def __init__(self):
+        self.model = None
+
+    def set_model(self, model):
+        self.model = model
+
+    def on_train_begin(self, logs=None):
+        pass
+
+    def on_train_end(self, logs=None):
+        pass
+
+    def on_epoch_begin(self, epoch, logs=None):
+        pass
+
+    def on_epoch_end(self, epoch, logs=None):
+        pass
+
+    def on_batch_begin(self, batch, logs=None):
+        pass
+
+    def on_batch_end(self, batch, logs=None):
+        pass
+
+
+class ModelCheckpoint(Callback):
+    """keras.callbacks.ModelCheckpoint(filepath, verbose=0, save_best_only=False, monitor='val_loss', mode='auto', period=1):
+    `filepath` may contain {epoch:02d} and the keys of `logs`; with save_best_only the file is written when `monitor`
+    improves (mode 'auto': 'max' for names containing 'acc' or starting with 'fmeasure', else 'min')."""
+
+    def __init__(self, filepath, monitor="val_loss", verbose=0, save_best_only=False, save_weights_only=False, mode="auto", period=1):
+        super(ModelCheckpoint, self).__init__()
+        self.filepath, self.monitor, self.verbose = filepath, monitor, verbose
+        self.save_best_only, self.period, self.epochs_since_last_save = save_best_only, int(period), 0
+        if mode not in ("auto", "min", "max"):
+            mode = "auto"
+        if mode == "auto":
+            mode = "max" if ("acc" in monitor or monitor.startswith("fmeasure")) else "min"
+        self.better = (lambda a, b: a > b) if mode == "max" else (lambda a, b: a < b)
+        self.best = -float("inf") if mode == "max" else float("inf")
+
+    def on_epoch_end(self, epoch, logs=None):
+        logs = logs or {}
+        self.epochs_since_last_save += 1
+        if self.epochs_since_last_save < self.period:
+            return
+        self.epochs_since_last_save = 0
+        path = self.filepath.format(epoch=epoch + 1, **logs)
+        if self.save_best_only:
+            cur = logs.get(self.monitor)
+            if cur is None or not self.better(cur, self.best):
+                return
+            self.best = cur
+        if self.verbose:
+            print("\nEpoch %05d: saving model to %s" % (epoch + 1, path))
+        self.model.save(path)
+
+
+class RedirectModel(Callback):
+    """callbacks/common.py:4-47: wraps another callback, executed on a different model."""
+
+    def __init__(self, callback, model):
+        super(RedirectModel, self).__init__()
+        self.callback, self.redirect_model = callback, model
+
+    def on_epoch_begin(self, epoch, logs=None):
+        self.callback.on_epoch_begin(epoch, logs=logs)
+
+    def on_epoch_end(self, epoch, logs=None):
+        self.callback.on_epoch_end(epoch, logs=logs)
+
+    def on_batch_begin(self, batch, logs=None):
+        self.callback.on_batch_begin(batch, logs=logs)
+
+    def on_batch_end(self, batch, logs=None):
+        self.callback.on_batch_end(batch, logs=logs)
+
+    def on_train_begin(self, logs=None):
+        self.callback.set_model(self.redirect_model)  # overwrite the model with our custom model
+        self.callback.on_train_begin(logs=logs)
+
+    def on_train_end(self, logs=None):
+        self.callback.on_train_end(logs=logs)

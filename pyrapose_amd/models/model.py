@@ -107,9 +107,11 @@ class PyraPoseModel(object):
         """``.npz`` written by save_weights (keys = '<layer>/kernel' HWIO, '<layer>/bias', '<bn>/...').  Keras
         ``.h5`` files need h5py, which this image does not have: convert them with
         ``python -c "import h5py, numpy ..."`` on a machine that does."""
-        if str(filepath).endswith(".h5"):
+        with open(filepath, "rb") as f:
+            magic = f.read(8)
+        if magic.startswith(b"\x89HDF"):  # a real Keras / HDF5 file (whatever its name)
             raise ImportError("load_weights: reading Keras .h5 needs h5py (not installed); convert to .npz (INTEGRATION.md)")
-        data = np.load(filepath)
+        data = np.load(filepath)  # the zip container of save_weights -- also under the '.h5' names of ModelCheckpoint
         W = OrderedDict(self.get_weights_dict())
         for k in data.files:
             if k not in W:
@@ -127,7 +129,9 @@ class PyraPoseModel(object):
             self._engine.refresh_planes()
 
     def save_weights(self, filepath):
-        np.savez(filepath, **self.get_weights_dict())
+        """numpy container, written under exactly the given name (the reference's snapshot names end in '.h5')."""
+        with open(filepath, "wb") as f:
+            np.savez(f, **self.get_weights_dict())
 
     save = save_weights
 
@@ -199,6 +203,9 @@ class PyraPoseModel(object):
                     cb.on_epoch_end(epoch, logs)
             if self.stop_training:
                 break
+        for cb in callbacks:
+            if hasattr(cb, "on_train_end"):
+                cb.on_train_end()
         return history
 
     # learning-rate access for ReduceLROnPlateau-style callbacks

@@ -1,0 +1,63 @@
+"""CPU: the callbacks of bin/train.py:107-155 -- ModelCheckpoint under the reference's snapshot names, RedirectModel
+(callbacks/common.py), ReduceLROnPlateau -- and the name-agnostic weight container (no GPU needed: no engine is built)."""
+import os
+
+import numpy as np
+import pytest
+
+from pyrapose_amd import callbacks, models, optimizers
+
+
+def test_model_checkpoint_redirect_and_reload(tmp_path):
+    model = models.backbone("resnet50").retinanet(num_classes=4)
+    other = models.backbone("resnet50").retinanet(num_classes=4)  # stands in for the wrapped / parallel training model
+    name = os.path.join(str(tmp_path), "{backbone}_{dataset_type}_{{epoch:02d}}.h5".format(backbone="resnet50", dataset_type="linemod"))
+    cp = callbacks.RedirectModel(callbacks.ModelCheckpoint(name), model)  # bin/train.py:131-143
+    cp.set_model(other)
+    cp.on_train_begin()
+    assert cp.callback.model is model  # redirected
+    cp.on_epoch_end(0, {"loss": 1.0})
+    cp.on_epoch_end(1, {"loss": 0.5})
+    files = sorted(os.listdir(str(tmp_path)))
+    assert files == ["resnet50_linemod_01.h5", "resnet50_linemod_02.h5"]  # exactly the reference's names
+    loaded = models.load_model(os.path.join(str(tmp_path), files[1]), backbone_name="resnet50")
+    w0, w1 = model.get_weights_dict(), loaded.get_weights_dict()
+    assert set(w0) == set(w1) and all(np.array_equal(w0[k], w1[k]) for k in w0)
+    assert w0["reg_conv0/kernel"].shape == (3, 3, 256, 512)  # Keras HWIO
+
+
+def test_checkpoint_save_best_only_and_period(tmp_path):
+    model = models.backbone("resnet50").retinanet(num_classes=2)
+    cp = callbacks.ModelCheckpoint(os.path.join(str(tmp_path), "best.h5"), monitor="loss", save_best_only=True)
+    cp.set_model(model)
+    for epoch, loss in enumerate([3.0, 2.0, 2.5, 1.0]):
+        before = os.path.getmtime(cp.filepath) if os.path.exists(cp.filepath) else None
+        cp.on_epoch_end(epoch, {"loss": loss})
+        if loss == 2.5:
+            assert os.path.getmtime(cp.filepath) == before  # no improvement, no write
+    assert cp.best == 1.0
+    every2 = callbacks.ModelCheckpoint(os.path.join(str(tmp_path), "e{epoch:02d}.h5"), period=2)
+    every2.set_model(model)
+    for epoch in range(4):
+        every2.on_epoch_end(epoch, {})
+    assert sorted(f for f in os.listdir(str(tmp_path)) if f.startswith("e")) == ["e02.h5", "e04.h5"]
+
+
+def test_real_hdf5_is_refused_by_content_not_by_name(tmp_path):
+    model = models.backbone("resnet50").retinanet(num_classes=2)
+    p = os.path.join(str(tmp_path), "keras.h5")
+    with open(p, "wb") as f:
+        f.write(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
+    with pytest.raises(ImportError):
+        model.load_weights(p)
+
+
+def test_reduce_lr_on_plateau_schedule():
+    model = models.backbone("resnet50").retinanet(num_classes=2)
+    model.compile(loss={"3Dbox": __import__("pyrapose_amd").losses.orthogonal_l1(), "cls": __import__("pyrapose_amd").losses.focal(),
+                        "mask": __import__("pyrapose_amd").losses.focal()}, optimizer=optimizers.Adam(lr=1e-4, clipnorm=0.001))
+    cb = callbacks.ReduceLROnPlateau(monitor="loss", factor=0.1, patience=2, verbose=0, min_delta=0.0001)  # bin/train.py:145-154
+    cb.set_model(model)
+    for epoch, loss in enumerate([1.0, 0.9, 0.9, 0.9, 0.9]):
+        cb.on_epoch_end(epoch, {"loss": loss})
+    assert model.lr == pytest.approx(1e-5)
