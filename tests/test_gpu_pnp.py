@@ -117,3 +117,58 @@ def test_poses_from_prediction_outputs(ctx):
     assert pose_decode.poses_from_outputs(boxes3D, scores, corners, Kmat, threshold=0.995, ctx=ctx) == []
     one = pose_decode.poses_from_outputs(boxes3D, scores, corners, Kmat, min_votes=1, ctx=ctx)  # occlusion_eval.py:359-371
     assert [(o["image"], o["cls"]) for o in one] == [(0, 0), (0, 2), (1, 1), (1, 2)]
+
+
+def test_evaluate_add_loop_on_a_scripted_network(ctx):
+    """utils.eval_pose.evaluate_add (the arithmetic of utils/linemod_eval.py:263-660) with a scripted 'network': votes around
+    the ground-truth pose give a true pose, votes around a wrong pose a detection without one, too few votes nothing."""
+    from oracle import pnp_np as P
+    from pyrapose_amd.utils import eval_pose
+    from tests.test_oracle_pnp import project
+    rng = np.random.default_rng(12)
+    C, N, H, W = 3, 2000, 480, 640
+    boxes = np.stack([BOX, BOX * 0.8, BOX * 1.1]) * 0.001           # metres, like the reference's threeD_boxes
+    pts = [rng.uniform(-1, 1, (300, 3)) * np.abs(b).max(0) for b in boxes]
+    dia = [float(np.linalg.norm(b.max(0) - b.min(0))) for b in boxes]
+
+    def axis_angle_to_quat(w):
+        th = np.linalg.norm(w)
+        return np.concatenate([[np.cos(th / 2)], np.sin(th / 2) * w / th])
+
+    cases = []  # (label, gt quaternion, gt t [mm], what the network votes for)
+    for lab, kind in ((0, "good"), (1, "wrong"), (2, "few"), (1, "good")):
+        w = rng.normal(size=3)
+        t = np.array([rng.uniform(-100, 100), rng.uniform(-80, 80), rng.uniform(600, 1000)])
+        cases.append((lab, axis_angle_to_quat(w), t, kind))
+
+    class Gen(object):
+        def size(self): return len(cases)
+        def load_image(self, i): return np.full((H, W, 3), i, np.uint8)
+        def preprocess_image(self, x): return x.astype(np.float32)
+        def resize_image(self, x): return x, 1.0
+        def load_annotations(self, i):
+            lab, q, t, _ = cases[i]
+            return {"labels": np.array([float(lab)]), "poses": np.array([np.concatenate([t, q])])}
+
+    def predict(x):
+        i = int(x[0, 0, 0, 0])
+        lab, q, t, kind = cases[i]
+        R = eval_pose.quat2mat(q)
+        if kind == "wrong":
+            R = P.so3_exp(np.array([0.0, 0.0, 1.2])) @ R
+        k = 5 if kind == "few" else 40
+        uv = project(R, t * 0.001, boxes[lab])
+        b3 = rng.uniform(0, 600, (1, N, 16)).astype(np.float32)
+        sc = rng.uniform(0, 0.2, (1, N, C)).astype(np.float32)
+        anchors = np.sort(rng.choice(N, k, replace=False))
+        b3[0, anchors] = (uv[None] + rng.normal(scale=0.8, size=(k, 8, 2))).reshape(k, 16)
+        sc[0, anchors, lab] = 0.9
+        return [b3, sc, np.zeros((1, 4800, C), np.float32)]
+
+    out = eval_pose.evaluate_add(Gen(), predict, boxes, pts, dia, symmetric_classes=(2,))
+    assert out["allPoses"].tolist() == [0, 1, 2, 1]
+    assert out["trueDets"].tolist() == [0, 1, 2, 0] and out["truePoses"].tolist() == [0, 1, 1, 0]
+    assert out["recall"][1] == 1.0 and out["recall"][2] == 0.5 and out["recall"][3] == 0.0
+    assert abs(out["recall_all"] - 0.5) < 1e-12 and len(out["errors"]) == 3
+    assert np.allclose(eval_pose.quat2mat([1, 0, 0, 0]), np.eye(3))
+    assert np.allclose(eval_pose.quat2mat(axis_angle_to_quat(np.array([0.3, -0.2, 0.9]))), P.so3_exp(np.array([0.3, -0.2, 0.9])), atol=1e-12)
