@@ -94,3 +94,24 @@ class RedirectModel(Callback):
 
     def on_train_end(self, logs=None):
         self.callback.on_train_end(logs=logs)
+
+
+class PoseEval(Callback):
+    """callbacks/linemod.py LinemodEval (created at bin/train.py:114-124 and wrapped in RedirectModel(evaluation,
+    prediction_model)): at the end of every epoch run the pose evaluation on the validation generator with the prediction
+    model and put the rates into `logs` (keys 'recall' and 'detections'; the per-class arrays stay in `self.last`)."""
+
+    def __init__(self, generator, threeD_boxes, model_points, model_diameters, K=None, threshold=0.5, min_votes=10,
+                 symmetric_classes=(), tensorboard=None, verbose=1):
+        super(PoseEval, self).__init__()
+        self.generator, self.verbose, self.last = generator, verbose, None
+        self.kw = dict(threeD_boxes=threeD_boxes, model_points=model_points, model_diameters=model_diameters, K=K, threshold=threshold,
+                       min_votes=min_votes, symmetric_classes=symmetric_classes)
+
+    def on_epoch_end(self, epoch, logs=None):
+        from .utils.eval_pose import evaluate_add
+        self.last = evaluate_add(self.generator, self.model.predict_on_batch, **self.kw)
+        if logs is not None:
+            logs["recall"], logs["detections"] = self.last["recall_all"], self.last["detections_all"]
+        if self.verbose:
+            print("epoch %d: ADD(-S) recall %.4f, detections %.4f" % (epoch + 1, self.last["recall_all"], self.last["detections_all"]))

@@ -165,6 +165,23 @@ def test_evaluate_add_loop_on_a_scripted_network(ctx):
         sc[0, anchors, lab] = 0.9
         return [b3, sc, np.zeros((1, 4800, C), np.float32)]
 
+    # the same through the epoch-end callback of bin/train.py:114-124 (LinemodEval wrapped in RedirectModel)
+    from pyrapose_amd import callbacks
+
+    class PredictionModel(object):
+        predict_on_batch = staticmethod(predict)
+
+    ev = callbacks.RedirectModel(callbacks.PoseEval(Gen(), boxes, pts, dia, symmetric_classes=(2,), verbose=0), PredictionModel())
+    ev.on_train_begin()
+    logs = {"loss": 1.0}
+    ev.on_epoch_end(0, logs)
+    assert abs(logs["recall"] - 0.5) < 1e-12 and abs(logs["detections"] - 2.0 / 3.0) < 1e-12
+    rng = np.random.default_rng(12)  # replay the same scripted outputs for the direct call
+    cases.clear()
+    for lab, kind in ((0, "good"), (1, "wrong"), (2, "few"), (1, "good")):
+        w = rng.normal(size=3)
+        t = np.array([rng.uniform(-100, 100), rng.uniform(-80, 80), rng.uniform(600, 1000)])
+        cases.append((lab, axis_angle_to_quat(w), t, kind))
     out = eval_pose.evaluate_add(Gen(), predict, boxes, pts, dia, symmetric_classes=(2,))
     assert out["allPoses"].tolist() == [0, 1, 2, 1]
     assert out["trueDets"].tolist() == [0, 1, 2, 0] and out["truePoses"].tolist() == [0, 1, 1, 0]
