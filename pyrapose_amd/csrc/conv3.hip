@@ -598,7 +598,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
 // Where the time goes (profiles/r01_pmc_stalls.txt, 128x128): MFMA pipe 58 % busy, VALU 19 % (8 % under an MFMA), LDS unit
 // 34 %, no bank conflicts; for 31 % of the cycles all three resident waves of a SIMD wait (barriers, LDS / global
 // latency).  Tried against that: a double-buffered weight tile (one barrier per tap instead of two, 48 KB of LDS): the
-// kernel alone gains 1 %, the training step loses 1 % (less room for the other lane's workgroups on the CU) -- not kept.
+// kernel alone gains 1 %, the training step loses 1 % (less room for the other lane's workgroups on the CU) -- not kept;
+// s_setprio 2 / 0 around the MFMA bursts (the hipBLASLt habit): 1 % slower alone and in the step.
 // CAP: the bf16 (hi, lo) split of the gathered f32 operand is also written out ([rows][ld_src] planes, the geometry of
 // pp_split_planes_bf16x3): for the centre kernel row (dy = 0: the staged rows are the tile's own rows; the BM - 2 inner
 // rows of all tiles cover every row once) the workgroups store the registers they have just converted, the output-channel
