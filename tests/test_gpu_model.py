@@ -488,7 +488,7 @@ def test_sparse_backward_of_box_head_matches_dense(ctx, monkeypatch):
     print("active / total 32-row blocks per layer:", dict(zip(got["reg"][2], got["reg"][3])))
     assert all(0 < a < n for a, n in got["reg"][3])  # some blocks, not all
     for k in ("3Dbox", "cls", "mask"):  # (the loss sums are float32 atomics: equal to rounding)
-        assert abs(got["0"][1][k] - got["reg"][1][k]) <= 1e-6 * abs(got["0"][1][k])
+        assert abs(got["0"][1][k] - got["reg"][1][k]) <= 2e-5 * abs(got["0"][1][k])  # float32 atomics in the loss sums
     g0, g1 = got["0"][0].double(), got["reg"][0].double()
     # (the listed-block data gradient is another kernel than the dense one: float32 summation order, a few 1e-6 after 5 layers)
     assert float((g0 - g1).norm() / g0.norm()) < 2e-5 and float((g0 - g1).abs().max() / g0.abs().max()) < 1e-4
@@ -522,6 +522,6 @@ def test_sparse_backward_full_size_bench_config(ctx, monkeypatch):
         torch.cuda.empty_cache()
     assert got["0"][2] == [] and len(got["reg"][2]) == 5 and 0 < max(got["reg"][2]) < 0.25
     for k in ("3Dbox", "cls", "mask"):
-        assert abs(got["0"][1][k] - got["reg"][1][k]) <= 1e-6 * abs(got["0"][1][k])
+        assert abs(got["0"][1][k] - got["reg"][1][k]) <= 2e-5 * abs(got["0"][1][k])  # float32 atomics in the loss sums
     g0, g1 = got["0"][0].double(), got["reg"][0].double()
     assert float((g0 - g1).norm() / g0.norm()) < 2e-5 and float((g0 - g1).abs().max() / g0.abs().max()) < 1e-4
