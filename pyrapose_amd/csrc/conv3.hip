@@ -60,6 +60,7 @@ __device__ __forceinline__ int div_small(int a, int b, float rcp_b, int* rem) {
 }
 
 // ---- epilogue through LDS (see conv.hip), shared by both main loops ----
+// (Measured and not kept: non-temporal stores for the output tile -- the next launch reads it back, and the step lost 1 %.)
 // RL: the tile's BM rows are BM / 32 listed 32-row blocks (rl_blk[j] = first row of block j of this tile, >= M when the
 // list has ended) instead of the consecutive rows m0 ..
 template <int TM, int TN, bool OP, int GOP = 1, bool SC = false, bool XR = false, bool RL = false>
