@@ -793,7 +793,10 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3x_kernel(
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
         }
-      if (s == 0) __builtin_amdgcn_sched_barrier(0);
+      // scheduling hint: interleave the LDS fragment reads of this half-step with its MFMAs (measured on the head shapes: +3 %
+      // over a plain barrier between the two halves, +1.7 % in the training step; the same hint makes igemm3f's 256x128 tile
+      // and the large weight-gradient launches 2 % slower, so it stays here only)
+      __builtin_amdgcn_iglp_opt(1);
     }
   };
 
