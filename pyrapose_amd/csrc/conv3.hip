@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
 // to a third.  Loop order: ty, channel chunk, tx (unrolled: the body of each tx is one basic block).
 // Conditions (host-checked): kw == 3, stride 1, source space == enumerated space (SH == OH, SW == OW, same row offsets),
 // f32 source, no planes / scatter.
-// Where the time goes (profiles/r01_pmc_stalls.txt, 128x128): MFMA pipe 58 % busy, VALU 19 % (8 % under an MFMA), LDS unit
+// Where the time went before the iglp_opt hint below (profiles/r01_pmc_stalls.txt, 128x128; 65 % MFMA-busy with it): MFMA pipe 58 % busy, VALU 19 % (8 % under an MFMA), LDS unit
 // 34 %, no bank conflicts; for 31 % of the cycles all three resident waves of a SIMD wait (barriers, LDS / global
 // latency).  Tried against that: a double-buffered weight tile (one barrier per tap instead of two, 48 KB of LDS): the
 // kernel alone gains 1 %, the training step loses 1 % (less room for the other lane's workgroups on the CU) -- not kept;
