@@ -1087,6 +1087,16 @@ static bool igemm3_fast_ok(const IgemmParams& p, bool planes, int w_rows, int w_
          (long long)max_sw * p.ld_src * 4 < (1ll << 23) && p.src_rows > 0;
 }
 
+// the tap-row-reuse kernel applies: 3-wide stride-1 "same" geometry on an f32 operand (conditions of igemm3x_kernel)
+static bool igemm3x_ok(const IgemmParams& p, bool planes_in, bool planes_out, int w_rows, int w_ld8) {
+  static const bool x_on = []() { const char* e = getenv("PP_CONV3_XREUSE"); return !(e && e[0] == '0'); }();
+  bool same = x_on && igemm3_fast_ok(p, planes_in, w_rows, w_ld8) && !planes_in && !planes_out && !p.sc_on && p.kw == 3 && p.mul == 1 &&
+              p.div == 1 && p.src != nullptr && p.w_tstep == 1 && p.w_tx0 == 0;
+  for (int i = 0; i < p.n_seg && same; ++i)
+    same = p.seg[i].OH == p.seg[i].SH && p.seg[i].OW == p.seg[i].SW && p.seg[i].row_begin == p.seg[i].src_row_begin;
+  return same;
+}
+
 // ---- sparse data gradient of a 3x3 stride-1 conv: which 32-row OUTPUT blocks can a non-zero of dy reach? ----
 // Output row m reads dy rows m + dy * W + dx, dy, dx in {-1, 0, 1} (W = width of m's level): block b is live when a flagged
 // dy block intersects one of the three 34-row windows [32 b - 1 + j W, 32 b + 32 + j W], j = -1, 0, 1 -- exact in 2-D up to
@@ -1179,12 +1189,7 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
     return;
   }
   if constexpr (TM <= 2) {
-    static const bool x_on = []() { const char* e = getenv("PP_CONV3_XREUSE"); return !(e && e[0] == '0'); }();
-    bool same = fast && x_on && !ahi && !ohi && !p.sc_on && p.kw == 3 && p.mul == 1 && p.div == 1 && p.src != nullptr &&
-                p.w_tstep == 1 && p.w_tx0 == 0;
-    for (int i = 0; i < p.n_seg && same; ++i)
-      same = p.seg[i].OH == p.seg[i].SH && p.seg[i].OW == p.seg[i].SW && p.seg[i].row_begin == p.seg[i].src_row_begin;
-    if (same) {
+    if (igemm3x_ok(p, ahi != nullptr, ohi != nullptr, w_rows, w_ld8)) {
       const int n_tiles_mx = (p.M + BM - 3) / (BM - 2);  // tiles overlap by two rows
       int skip_halo = 0;
       for (int i = 0; i < p.n_seg; ++i) skip_halo = p.seg[i].SW + 1 > skip_halo ? p.seg[i].SW + 1 : skip_halo;
@@ -1217,7 +1222,7 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
   else go(std::false_type{}, std::false_type{});
 }
 
-static void pick_tile3(const pp_ctx* ctx, int M, int Nout, int ld_out, int n_steps, bool may_split, int* tm, int* tn, int* splits) {
+static void pick_tile3(const pp_ctx* ctx, int M, int Nout, int ld_out, int n_steps, bool may_split, bool x_ok, int* tm, int* tn, int* splits) {
   // measured in-flight rates relative to 128x128 (tools/conv_bench.py): the LDS store path (ds_write_b128 of the
   // staged tiles) costs ~30 % of the loop, so the tile with the fewest staged bytes per MFMA wins when it fills the chip.
   // A workgroup costs (its k-steps + ~8 steps' worth of prologue, epilogue and launch ramp) x tile area; splitting the
@@ -1252,6 +1257,13 @@ static void pick_tile3(const pp_ctx* ctx, int M, int Nout, int ld_out, int n_ste
       }
     }
   }
+  // the 256x128 tile has no tap-row-reuse variant: where that kernel applies, 128x128 with reuse wins (measured on the
+  // 256-channel class head, 50400 rows: 194-207 us against 205-227 us; a reuse bonus inside the model above instead sent
+  // that shape to 64x128 and the step lost 2 %)
+  if (x_ok && *tm == 4 && *splits == 1) {
+    *tm = 2;
+    *tn = 2;
+  }
   const char* e = getenv("PP_CONV3_TILE");
   if (e && e[0] && e[1] == ',' && e[2]) {
     *tm = e[0] - '0';
@@ -1268,7 +1280,7 @@ static void dispatch3(pp_ctx* ctx, IgemmParams& p, const void* ahi, const void* 
   int tm, tn, splits;
   const int n_steps = p.kh * p.kw * (p.Cred / 32);
   const bool may_split = ctx->ws != nullptr && !ohi && p.out != nullptr && !p.sc_on && igemm3_fast_ok(p, ahi != nullptr, w_rows, w_ld8);
-  pick_tile3(ctx, p.M, p.Nout, p.ld_out, n_steps, may_split, &tm, &tn, &splits);
+  pick_tile3(ctx, p.M, p.Nout, p.ld_out, n_steps, may_split, igemm3x_ok(p, ahi != nullptr, ohi != nullptr, w_rows, w_ld8), &tm, &tn, &splits);
   if (getenv("PP_CONV_DEBUG")) fprintf(stderr, "igemm3 M %d N %d steps %d -> tile %dx%d splits %d\n", p.M, p.Nout, n_steps, 64 * tm, 64 * tn, splits);
   float* ws = splits > 1 ? ctx->ws : nullptr;
   if (tm == 4) launch_igemm3<4, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo, flags);
