@@ -1281,7 +1281,9 @@ static void dispatch3(pp_ctx* ctx, IgemmParams& p, const void* ahi, const void* 
   const int n_steps = p.kh * p.kw * (p.Cred / 32);
   const bool may_split = ctx->ws != nullptr && !ohi && p.out != nullptr && !p.sc_on && igemm3_fast_ok(p, ahi != nullptr, w_rows, w_ld8);
   pick_tile3(ctx, p.M, p.Nout, p.ld_out, n_steps, may_split, igemm3x_ok(p, ahi != nullptr, ohi != nullptr, w_rows, w_ld8), &tm, &tn, &splits);
-  if (getenv("PP_CONV_DEBUG")) fprintf(stderr, "igemm3 M %d N %d steps %d -> tile %dx%d splits %d\n", p.M, p.Nout, n_steps, 64 * tm, 64 * tn, splits);
+  if (getenv("PP_CONV_DEBUG"))
+    fprintf(stderr, "igemm3 M %d N %d steps %d -> tile %dx%d splits %d (may_split %d: ws %d planes_out %d out %d)\n", p.M, p.Nout, n_steps, 64 * tm,
+            64 * tn, splits, (int)may_split, (int)(ctx->ws != nullptr), (int)(ohi != nullptr), (int)(p.out != nullptr));
   float* ws = splits > 1 ? ctx->ws : nullptr;
   if (tm == 4) launch_igemm3<4, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo, flags);
   else if (tm == 2 && tn == 2) launch_igemm3<2, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo, flags);
