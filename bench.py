@@ -19,14 +19,15 @@ reference cannot run here or on the GPU box -- tensorflow/keras are not installe
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# numpy / torch are imported by the worker (main_worker); the N > 1 parent (spawn_ranks) imports neither and makes no
+# GPU call: it only starts one child process per rank and relays rank 0's line.
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # dense f32 MFMA, MI355X_MICROARCH.md
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (never the 2:1-sparsity figure)
@@ -50,6 +51,7 @@ def measured_peak(mode, achieved):
 
 def synth_batch(B, H, W, C, seed, side=(40, 160)):
     """images uint8 U[0,255] - caffe means; K~U{1..3} boxes, sides U[40,160]."""
+    import numpy as np
     rng = np.random.default_rng(seed)
     x = rng.integers(0, 256, size=(B, H, W, 3)).astype(np.float32) - np.array([103.939, 116.779, 123.68], np.float32)
     anns, images = [], []
@@ -79,7 +81,183 @@ def synth_batch(B, H, W, C, seed, side=(40, 160)):
     return x, images, anns
 
 
-def main():
+def cpu_baseline(weights, x, anns, targets, C, H, W, n_timed=3):
+    """The CPU leg (rank 0, N=1): the oracle's PyTorch-CPU float32 train step on a 1-image sample of the same batch
+    (one warm-up step, then n_timed timed steps), plus the oracle's anchors_for_shape + anchor_targets_bbox on the whole
+    batch, single thread (the reference's numpy/Cython path holds the GIL: SURVEY 8d).  kind = "port": the Keras/TF
+    reference cannot run here (tensorflow / keras are not installed)."""
+    import platform
+    from oracle import anchors_np as AN
+    from oracle import model_torch as MT
+    nb = 1
+    yb, yc, ym = (t[:nb].cpu().numpy() for t in targets)
+
+    def step():
+        _, grads, _ = MT.loss_and_grads(weights, x[:nb], yb, yc, ym, C, torch.float32)
+        m = {k: torch.zeros_like(g) for k, g in grads.items()}
+        v = {k: torch.zeros_like(g) for k, g in grads.items()}
+        MT.adam_clipnorm_step(weights, grads, m, v, 1)
+    step()  # warm-up: first-touch, autograd graph construction, thread pool
+    times = []
+    for _ in range(n_timed):
+        t1 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t1)
+    cpu_dt = sum(times) / len(times)
+    # anchor / target leg, single thread
+    nthr = torch.get_num_threads()
+    cpu_model = platform.processor() or ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    B = len(anns)
+    shapes = [(H, W, 3)] * B
+    AN.anchors_for_shape((H, W))
+    t1 = time.perf_counter()
+    for _ in range(3):
+        anc = AN.anchors_for_shape((H, W))
+    t_anchor = (time.perf_counter() - t1) / 3
+    AN.anchor_targets_bbox(anc, shapes, anns, C)
+    t1 = time.perf_counter()
+    for _ in range(2):
+        AN.anchor_targets_bbox(anc, shapes, anns, C)
+    t_targets = (time.perf_counter() - t1) / 2
+    return {"value": nb / cpu_dt, "unit": "images/sec", "cores": nthr, "kind": "port", "cpu_model": cpu_model,
+            "step_seconds": times,
+            "sample": "train step (fwd+loss+bwd+Adam) on %d image of the same synthetic batch, PyTorch-CPU float32 restatement "
+                      "(oracle/model_torch.py), not Keras: 1 warm-up + %d timed steps, mean" % (nb, n_timed),
+            "anchors_targets": {"anchors_for_shape_ms": 1e3 * t_anchor, "anchor_targets_bbox_ms_per_batch": 1e3 * t_targets,
+                                "batch": B, "threads": 1, "kind": "port (oracle/anchors_np.py, numpy float64; pinned bit-exact "
+                                "to the reference's utils/anchors.py by tests/golden)"}}
+
+
+def inference_leg(ctx, mode, B=32, C=8, H=480, W=640, steps=6, warmup=2):
+    """BASELINE configs[2] / SURVEY 8d config 3: Occlusion-style inference, batch 32, 8 classes: forward + device anchors (D1) +
+    box3D decode (D2) + score > 0.5 compaction (D3), and the same plus filter_detections (D4: NMS / top-300) -- timed
+    with HIP events on the ctx stream.  The final cls bias is shifted so that ~1 % of the scores pass 0.5 (seeded)."""
+    from pyrapose_amd import arch, ops
+    from pyrapose_amd.engine import Engine
+    Wt = arch.init_weights(C, seed=0)
+    rng = np.random.default_rng(0)
+    x = torch.as_tensor(rng.integers(0, 256, (B, H, W, 3)).astype(np.float32) - np.array([103.939, 116.779, 123.68], np.float32)).cuda()
+    probe = Engine(ctx, C, 1, H, W, weights=Wt, train=False, conv_mode=mode)
+    _, sc, _ = probe.predict_on_batch(x[:1])
+    q = float(torch.quantile(torch.logit(sc.flatten()[:: 7].double().clamp(1e-7, 1 - 1e-7)), 0.99))
+    Wt["cls_out/bias"] = (np.asarray(Wt["cls_out/bias"]) - q).astype(np.float32)
+    del probe
+    eng = Engine(ctx, C, B, H, W, weights=Wt, train=False, conv_mode=mode)
+    N = eng.anchors_device_f32().shape[0]
+    res = {}
+
+    def step(nms):
+        boxes3d, scores, mask = eng.predict_on_batch(x)
+        idx = ops.score_threshold_compact(ctx, scores, 0.5)
+        if nms:
+            xs, ys = boxes3d[..., 0::2], boxes3d[..., 1::2]
+            boxes = torch.stack([xs.amin(-1), ys.amin(-1), xs.amax(-1), ys.amax(-1)], -1).contiguous()
+            ops.filter_detections_batch(ctx, boxes, boxes3d, scores, 0.05, 0.5, 300)
+        return scores
+    for nms in (False, True):
+        for _ in range(warmup):
+            scores = step(nms)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            scores = step(nms)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        res["decode_compact_nms" if nms else "decode_compact"] = {"value": B * 1e3 / ms, "unit": "images/sec", "ms_per_batch": ms,
+                                                                 "anchors_per_sec": B * N * 1e3 / ms}
+    res.update({"workload": "Occlusion-style inference, batch %d, %d classes, %dx%d, forward + anchors + box3D decode + score>0.5 "
+                            "compaction [+ filter_detections] (BASELINE configs[2])" % (B, C, W, H),
+                "frac_scores_over_0.5": float((scores > 0.5).float().mean()), "steps": steps, "warmup": warmup, "dtype": eng.conv_mode,
+                "n_gpus": 1, "data": "synthetic"})
+    del eng
+    torch.cuda.empty_cache()
+    return res
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n, argv, worker=None, timeout=None, env_extra=None):
+    """`bench.py --gpus N` started WITHOUT a launcher (WORLD_SIZE unset): start the N ranks ourselves.
+
+    This process has made no GPU call (torch is not even imported) and makes none: it starts one child per rank --
+    `python bench.py <same argv>` with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in the
+    environment, which is exactly what torch.distributed.run would export -- waits for them, relays rank 0's JSON line
+    and returns non-zero if any rank failed (the others are then terminated by PID; nothing is ever re-exec'd).
+    `worker` (tests): the argv prefix to run instead of [python, bench.py]."""
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    cmd = list(worker) if worker else [sys.executable, os.path.abspath(__file__)]
+    procs = []
+    import tempfile
+    out0 = tempfile.TemporaryFile(mode="w+")  # rank 0's stdout (a file, so a long line can never block on a pipe)
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port, "PP_BENCH_SPAWNED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=(out0 if r == 0 else subprocess.DEVNULL), stderr=None))
+    t_end = None if timeout is None else time.time() + timeout
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if t_end is not None and time.time() > t_end:
+            failed = (-1, "timeout")
+            break
+        time.sleep(0.05)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        sys.stderr.write("bench.py: rank %s failed (%s); %d-rank run aborted\n" % (failed[0], failed[1], n))
+        return 1
+    out0.seek(0)
+    out = out0.read()
+    line = None
+    for ln in out.splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            line = ln
+    if line is None:
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+        return 1
+    try:
+        got = json.loads(line).get("n_gpus")
+    except ValueError:
+        got = None
+    if got != n:
+        sys.stderr.write("bench.py: rank 0 reports n_gpus=%r, expected %d\n" % (got, n))
+        return 1
+    print(line)
+    sys.stdout.flush()
+    return 0
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -93,23 +271,46 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--dump-ops", default=None, help="write a per-launch table (name, kind, GFLOP, avg us, TFLOP/s)")
-    args = ap.parse_args()
+    ap.add_argument("--no-inference", action="store_true", help="skip the config-3 inference leg (B=32, C=8)")
+    return ap.parse_args(argv)
 
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: this process becomes the parent of N ranks (before torch is imported or any GPU call is made)
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    main_worker(args)
+
+
+def main_worker(args):
+    global np, torch
+    import numpy as np
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus N` (it spawns the ranks) or under "
+                         "torch.distributed.run --nproc-per-node N with the same N" % (args.gpus, world))
     import torch.distributed as dist
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # PP_DIST_BACKEND=gloo + fewer GPUs than ranks is a rehearsal mode (several ranks share a card); the driver's
         # scaling runs use the default: RCCL ("nccl"), one rank per GPU.
         backend = os.environ.get("PP_DIST_BACKEND", "nccl")
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+        n_dev = torch.cuda.device_count()
+        if backend == "nccl" and n_dev < world:
+            raise SystemExit("bench.py: %d ranks over RCCL need %d GPUs, %d visible (PP_DIST_BACKEND=gloo rehearses the N-rank "
+                             "path with several ranks per card)" % (world, world, n_dev))
+        local_rank = local_rank % max(n_dev, 1)
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     else:
         torch.cuda.set_device(0)
         local_rank = 0
@@ -280,18 +481,20 @@ def main():
             peak, kname = PEAK_BF16_MFMA_TFLOPS, "conv implicit-GEMM family (igemm3x / igemm3f fwd + bwd-data, wgrad3f): 3 x v_mfma_f32_32x32x16_bf16 per product, f32 accumulate"
         else:
             peak, kname = PEAK_F32_MFMA_TFLOPS, "conv implicit-GEMM family (igemm fwd/bwd-data + wgrad): v_mfma_f32_32x32x2_f32"
-        roofline = {"bound": "mfma", "achieved": roof["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": roof["achieved"] / peak,
+        mm = 3 if mode == "bf16x3" else 1
+        roofline = {"bound": "mfma", "achieved": roof["executed"], "peak": peak, "unit": "TFLOP/s", "frac": roof["executed"] / peak,
+                    "achieved_algorithmic": roof["achieved"], "frac_algorithmic": roof["achieved"] / peak,
                     "traffic": (traffic or {}).get("hbm_bytes_per_launch"), "traffic_detail": traffic, "kernel": kname,
-                    "method": "sum of ALGORITHMIC 2*MAC flops of every conv launch / union of their HIP-event intervals, on every %d-th step of "
-                              "the timed region (%d of %d steps; per-launch events on every step cost ~2.5 %% of the step time). "
-                              "executed_tflops / frac_executed credit the backward launches of the 3D-box head, which skip the zero blocks of "
-                              "their sparse gradient, only with the share of the reduction they run (sparse_backward.executed_share): that is "
-                              "the figure that speaks about MFMA efficiency"
+                    "method": "achieved / frac = EXECUTED 2*MAC flops of every conv launch / union of their HIP-event intervals (events on the "
+                              "launch streams), on every %d-th step of the timed region (%d of %d steps; per-launch events on every step "
+                              "cost ~2.5 %% of the step time).  Executed = algorithmic, except that the backward launches of the 3D-box "
+                              "head, which skip the zero blocks of their sparse gradient, are credited only with the share of the "
+                              "reduction they run (sparse_backward.executed_share).  achieved_algorithmic / frac_algorithmic count the "
+                              "skipped flops too (SURVEY 8d work per image): a statement about the step, not about the kernels"
                               % (EVENT_EVERY, roof["sampled_steps"], args.steps),
-                    "executed_tflops": roof["executed"], "frac_executed": roof["executed"] / peak,
-                    "mfma_flops_per_algorithmic_flop": 3 if mode == "bf16x3" else 1,
-                    "mfma_issue_frac": roof["executed"] * (3 if mode == "bf16x3" else 1) / peak,
-                    "vs_f32_mfma_peak_157.3": roof["achieved"] / PEAK_F32_MFMA_TFLOPS,
+                    "mfma_flops_per_algorithmic_flop": mm,
+                    "mfma_issue_frac": roof["executed"] * mm / peak,
+                    "vs_f32_mfma_peak_157.3": roof["executed"] / PEAK_F32_MFMA_TFLOPS,
                     "measured_peak": measured_peak(mode, roof["executed"]),
                     "dominant": roof["dominant"], "conv_share_of_step": roof["conv_share_of_step"], "lanes": roof["lanes"],
                     "per_kernel": roof["per_kernel"]}
@@ -318,23 +521,18 @@ def main():
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        from oracle import model_torch as MT
-        nb = 1
-        yb, yc, ym = (t[:nb].cpu().numpy() for t in (y_box, y_cls, y_mask))
-        t1 = time.perf_counter()
-        ref_losses, grads, _ = MT.loss_and_grads(weights, x[:nb], yb, yc, ym, C, torch.float32)
-        m = {k: torch.zeros_like(g) for k, g in grads.items()}
-        v = {k: torch.zeros_like(g) for k, g in grads.items()}
-        MT.adam_clipnorm_step(weights, grads, m, v, 1)
-        cpu_dt = time.perf_counter() - t1
-        cpu = {"value": nb / cpu_dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-               "sample": "1 train step (fwd+loss+bwd+Adam) on %d image of the same synthetic batch, PyTorch-CPU float32 "
-                         "restatement (oracle/model_torch.py), not Keras" % nb}
+        cpu = cpu_baseline(weights, x, anns, (y_box, y_cls, y_mask), C, H, W)
+
+    inference = None
+    if world == 1 and not args.no_inference:
+        inference = inference_leg(ctx, mode)
 
     out = {
         "metric": "images/sec 640x480 fwd+bwd (train step: fwd + losses + bwd + clipnorm-Adam)",
         "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "rccl_ranks": (world if backend == "nccl" else 0), "dist_backend": backend,
+        "value_dense_backward": ((sparse or {}).get("dense_backward") or {}).get("value"),
         "dtype": "bf16x3" if mode == "bf16x3" else "f32", "data": "synthetic", "sparse_backward": sparse,
         "dtype_note": ("every conv product = x_hi*w_hi + x_hi*w_lo + x_lo*w_hi on bf16 MFMA with f32 accumulation (2^-16 relative); "
                        "activations, master weights, losses and Adam in float32; head outputs within 1e-3 of the float64 oracle "
@@ -344,7 +542,7 @@ def main():
                    "algorithmic_gflop_per_image": algo_gflop},
         "step_tflops": images_total * algo_gflop / dt / 1e3,
         "losses": losses,
-        "roofline": roofline, "cpu_baseline": cpu, "other_mode": other,
+        "roofline": roofline, "cpu_baseline": cpu, "other_mode": other, "inference": inference,
     }
     print(json.dumps(out))
     if world > 1:
