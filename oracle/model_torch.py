@@ -72,7 +72,22 @@ def upsample_like(src, target):
     return src[:, :, iy][:, :, :, ix]
 
 
-def resnet50(x, W, dtype, blocks=None):
+def _relu(z, masks, name, level=None):
+    """ReLU, or -- when `masks` (name -> 0/1 tensor like z, or a list of them per pyramid level) is given -- multiplication by
+    a FIXED 0/1 pattern taken from another evaluation of the same graph.  The loss is piecewise smooth; two evaluations in
+    different arithmetic may put a pre-activation that is zero to rounding on different sides of the kink, after which
+    their gradients differ by O(1e-2) for a reason that has nothing to do with either implementation.  With the pattern
+    pinned, both differentiate the SAME smooth piece and can be compared tightly (tests only)."""
+    if masks is None:
+        return F.relu(z)
+    m = masks[name]
+    if level is not None:
+        m = m[level]
+    assert m.shape == z.shape, (name, level, tuple(m.shape), tuple(z.shape))
+    return z * m.to(z.dtype)
+
+
+def resnet50(x, W, dtype, blocks=None, relu_masks=None):
     """keras_resnet.models.ResNet50(include_top=False, freeze_bn=True) -> [C2, C3, C4, C5].
     blocks = [3, 4, 23, 3] gives the ResNet-101 variant (keras_resnet numerical_names [F, T, T, F]: blocks of
     stages 3 and 4 are named 'a', 'b1', 'b2', ...)."""
@@ -80,7 +95,7 @@ def resnet50(x, W, dtype, blocks=None):
     numerical = [False, True, True, False] if list(blocks) != RESNET50_BLOCKS else [False] * 4
     P = lambda n: _t(W[n + "/kernel"], dtype)
     y = conv2d(x, P("conv1"), None, 2, 3)                      # ZeroPadding2D(3) + 7x7/2 valid, no bias
-    y = F.relu(frozen_bn(y, W, "bn_conv1", dtype))
+    y = _relu(frozen_bn(y, W, "bn_conv1", dtype), relu_masks, "conv1")
     pt, pb = tf_same_pad(y.shape[2], 3, 2)                     # MaxPooling2D(3, 2, 'same')
     pl, pr = tf_same_pad(y.shape[3], 3, 2)
     y = F.max_pool2d(F.pad(y, (pl, pr, pt, pb), value=float("-inf")), 3, 2)
@@ -92,9 +107,9 @@ def resnet50(x, W, dtype, blocks=None):
             stride = 1 if (block != 0 or stage == 0) else 2  # Caffe style: stride on the first 1x1
             nm = lambda br: ("res%s%s_branch%s" % (sc, bc, br), "bn%s%s_branch%s" % (sc, bc, br))
             c, b = nm("2a")
-            z = F.relu(frozen_bn(conv2d(y, P(c), None, stride, 0), W, b, dtype))
+            z = _relu(frozen_bn(conv2d(y, P(c), None, stride, 0), W, b, dtype), relu_masks, c)
             c, b = nm("2b")
-            z = F.relu(frozen_bn(conv2d(z, P(c), None, 1, 1), W, b, dtype))   # ZeroPadding2D(1) + valid
+            z = _relu(frozen_bn(conv2d(z, P(c), None, 1, 1), W, b, dtype), relu_masks, c)   # ZeroPadding2D(1) + valid
             c, b = nm("2c")
             z = frozen_bn(conv2d(z, P(c), None, 1, 0), W, b, dtype)
             if block == 0:
@@ -102,7 +117,7 @@ def resnet50(x, W, dtype, blocks=None):
                 short = frozen_bn(conv2d(y, P(c), None, stride, 0), W, b, dtype)
             else:
                 short = y
-            y = F.relu(z + short)
+            y = _relu(z + short, relu_masks, "res%s%s" % (sc, bc))
         outs.append(y)
     return outs
 
@@ -124,7 +139,7 @@ def sparse_fpn(C3, C4, C5, W, dtype):
     return P3, P4, P5
 
 
-def pyramid_features(C3, C4, C5, W, dtype, with_p6p7=True):
+def pyramid_features(C3, C4, C5, W, dtype, with_p6p7=True, relu_masks=None):
     """models/retinanet.py:134-157 (__create_pyramid_features, P3..P7) / :160-177 (__create_FPN, P3..P5)."""
     def cv(name, x, k, s=1):
         return conv2d(x, _t(W[name + "/kernel"], dtype), _t(W[name + "/bias"], dtype), s, "same")
@@ -138,32 +153,34 @@ def pyramid_features(C3, C4, C5, W, dtype, with_p6p7=True):
     if not with_p6p7:
         return [P3, P4, P5]
     P6 = cv("P6_con", C5, 3, 2)                                         # :151 "3x3 stride-2 conv on C5"
-    P7 = cv("P7_con", F.relu(P6), 3, 2)                                 # :154-155
+    P7 = cv("P7_con", _relu(P6, relu_masks, "P6_relu"), 3, 2)                                 # :154-155
     return [P3, P4, P5, P6, P7]
 
 
-def head(prefix, feat, W, dtype, n_values):
+def head(prefix, feat, W, dtype, n_values, relu_masks=None, level=0):
     """4 x [3x3 conv + ReLU] + 3x3 conv, then Reshape((-1, n_values)) on NHWC."""
     y = feat
     for i in range(4):
-        y = F.relu(conv2d(y, _t(W["%s_conv%d/kernel" % (prefix, i)], dtype), _t(W["%s_conv%d/bias" % (prefix, i)], dtype)))
+        n = "%s_conv%d" % (prefix, i)
+        y = _relu(conv2d(y, _t(W[n + "/kernel"], dtype), _t(W[n + "/bias"], dtype)), relu_masks, n, level)
     y = conv2d(y, _t(W[prefix + "_out/kernel"], dtype), _t(W[prefix + "_out/bias"], dtype))
     return y.permute(0, 2, 3, 1).reshape(y.shape[0], -1, n_values)
 
 
-def forward(W, x_nhwc, num_classes, dtype=torch.float32, blocks=None, return_features=False, pyramid="sparse"):
+def forward(W, x_nhwc, num_classes, dtype=torch.float32, blocks=None, return_features=False, pyramid="sparse", relu_masks=None):
     """x_nhwc: (B,H,W,3) preprocessed image batch.  Returns dict with '3Dbox', 'cls', 'mask' (Keras
     outputs: cls/mask are probabilities) plus the pre-sigmoid logits."""
     x = _t(x_nhwc, dtype).permute(0, 3, 1, 2)
-    C2, C3, C4, C5 = resnet50(x, W, dtype, blocks)
+    C2, C3, C4, C5 = resnet50(x, W, dtype, blocks, relu_masks)
     if pyramid == "sparse":
         feats = list(sparse_fpn(C3, C4, C5, W, dtype))
     else:
-        feats = pyramid_features(C3, C4, C5, W, dtype, with_p6p7=(pyramid == "p3p7"))
+        feats = pyramid_features(C3, C4, C5, W, dtype, with_p6p7=(pyramid == "p3p7"), relu_masks=relu_masks)
     P3, P4, P5 = feats[:3]
-    reg = torch.cat([head("reg", f, W, dtype, 16) for f in feats], dim=1)
-    cls_logit = torch.cat([head("cls", f, W, dtype, num_classes) for f in feats], dim=1)
-    mask_logit = head("mask", P3, W, dtype, num_classes)
+    rm = relu_masks
+    reg = torch.cat([head("reg", f, W, dtype, 16, rm, l) for l, f in enumerate(feats)], dim=1)
+    cls_logit = torch.cat([head("cls", f, W, dtype, num_classes, rm, l) for l, f in enumerate(feats)], dim=1)
+    mask_logit = head("mask", P3, W, dtype, num_classes, rm, 0)
     out = {"3Dbox": reg, "cls": torch.sigmoid(cls_logit), "mask": torch.sigmoid(mask_logit),
            "cls_logit": cls_logit, "mask_logit": mask_logit}
     if return_features:
@@ -245,17 +262,22 @@ def trainable_names(W):
     return sorted(names)
 
 
-def loss_and_grads(W, x_nhwc, y_box, y_cls, y_mask, num_classes, dtype=torch.float64, blocks=None, pyramid="sparse"):
+def loss_and_grads(W, x_nhwc, y_box, y_cls, y_mask, num_classes, dtype=torch.float64, blocks=None, pyramid="sparse",
+                   relu_masks=None, loss_params=None):
     """Total Keras training loss = orthogonal_l1('3Dbox') + focal('cls') + focal('mask') + L2 reg
-    (bin/train.py:95-102), and its gradient w.r.t. every trainable tensor."""
+    (bin/train.py:95-102), and its gradient w.r.t. every trainable tensor.
+    relu_masks: see _relu (tests).  loss_params: dict(box=(weight, sigma), cls=(alpha, gamma), mask=(alpha, gamma)),
+    default = what bin/train.py:97-99 compiles."""
+    lp = dict(box=(0.125, 3.0), cls=(0.25, 2.0), mask=(0.25, 2.0))
+    lp.update(loss_params or {})
     names = trainable_names(W)
     Wt = {k: _t(v, dtype) for k, v in W.items()}
     for k in names:
         Wt[k].requires_grad_(True)
-    out = forward(Wt, x_nhwc, num_classes, dtype, blocks, pyramid=pyramid)
-    l_box = orthogonal_l1(_t(y_box, dtype), out["3Dbox"])
-    l_cls = focal(_t(y_cls, dtype), out["cls"])
-    l_mask = focal(_t(y_mask, dtype), out["mask"])
+    out = forward(Wt, x_nhwc, num_classes, dtype, blocks, pyramid=pyramid, relu_masks=relu_masks)
+    l_box = orthogonal_l1(_t(y_box, dtype), out["3Dbox"], *lp["box"])
+    l_cls = focal(_t(y_cls, dtype), out["cls"], *lp["cls"])
+    l_mask = focal(_t(y_mask, dtype), out["mask"], *lp["mask"])
     l_reg = sum(REG_L2 * (Wt[n + "/kernel"] ** 2).sum() for n in REG_L2_LAYERS)
     total = l_box + l_cls + l_mask + l_reg
     grads = torch.autograd.grad(total, [Wt[k] for k in names], allow_unused=True)

@@ -174,11 +174,23 @@ class ParamStore(object):
 
 class Engine(object):
     def __init__(self, ctx, num_classes, batch, height, width, backbone="resnet50", weights=None, train=True, seed=0,
-                 lr=1e-5, clipnorm=0.001, freeze_backbone=False, conv_mode=None, pyramid="sparse", anchor_params=None):
+                 lr=1e-5, clipnorm=0.001, freeze_backbone=False, conv_mode=None, pyramid="sparse", anchor_params=None,
+                 loss_params=None):
         """pyramid: 'sparse' (__create_sparceFPN, what the reference's retinanet() builds), 'fpn' (__create_FPN) or 'p3p7'
         (__create_pyramid_features: P3..P7).  anchor_params: utils.anchors.AnchorParameters (sizes / strides per level);
-        default: the reference default for 3 levels, the 5-level RetinaNet sizes 32..512 for 'p3p7'."""
+        default: the reference default for 3 levels, the 5-level RetinaNet sizes 32..512 for 'p3p7'.
+        loss_params: dict(box=(weight, sigma), cls=(alpha, gamma), mask=(alpha, gamma)) -- the hyper-parameters of the three
+        compiled losses (bin/train.py:95-102; defaults = the reference's: orthogonal_l1(0.125, 3.0), focal(0.25, 2.0))."""
+        # The engine owns a PRIVATE context bound to the stream that is current now: a later default_context() call under
+        # another torch stream re-binds the shared context, never this one, so lane 0 and the fork/join events of the other
+        # lanes always speak about the same stream.  Work of the caller's current stream is ordered around every public
+        # entry point by _enter() / _leave().
+        self._own_ctx = ops.Context(ctx.device, ctx.stream)
+        ctx = self._own_ctx
         self.ctx, self.C, self.B, self.H, self.W = ctx, int(num_classes), int(batch), int(height), int(width)
+        lp = dict(box=(0.125, 3.0), cls=(0.25, 2.0), mask=(0.25, 2.0))
+        lp.update(loss_params or {})
+        self.loss_params = {k: (float(v[0]), float(v[1])) for k, v in lp.items()}
         assert pyramid in arch.PYRAMIDS, pyramid
         self.pyramid = pyramid
         from .utils import anchors as _ua
@@ -265,6 +277,28 @@ class Engine(object):
             self._build_backward()
         self.grad_sync = None  # set by parallel.DataParallel
         self.refresh_planes()
+
+    def close(self):
+        """Release the native handles (contexts of every lane, optimizer state); the torch buffers go with the object."""
+        opt = getattr(self, "opt", None)
+        if opt is not None:
+            opt.close()
+            self.opt = None
+        for c in getattr(self, "ctxs", []):
+            c.close()
+        self.ctxs = []
+        self.fwd_ops, self.bwd_ops, self.graph_ops = [], [], []
+
+    def _enter(self):
+        """order the engine's lane 0 after the caller's current stream (no-op when they are the same stream)"""
+        cur = torch.cuda.current_stream(self.ctx.device)
+        if cur.cuda_stream != self.streams[0].cuda_stream:
+            self.streams[0].wait_stream(cur)
+        return cur
+
+    def _leave(self, cur):
+        if cur.cuda_stream != self.streams[0].cuda_stream:
+            cur.wait_stream(self.streams[0])
 
     # ------------------------------------------------------------------------------------ forward plan
     def _new_act(self, name, shapes, C, ld=None, needs_grad=False, relu=False, t=None):
@@ -773,9 +807,11 @@ class Engine(object):
             self.streams[0].wait_event(ev)
 
     def forward(self, x=None):
-        if x is not None:
-            self.x_in.copy_(x)
+        cur = self._enter()
         streams = self.streams
+        if x is not None:
+            with torch.cuda.stream(streams[0]):
+                self.x_in.copy_(x)
         for op in self.fwd_ops:
             st = streams[op.lane]
             for ev in op.waits:
@@ -784,12 +820,14 @@ class Engine(object):
             if op.done_ev is not None:
                 op.done_ev.record(st)
         self._join(list(range(1, self.n_lanes)))
+        self._leave(cur)
 
     def forward_u8(self, images_u8, sizes_hw=None):
         """Forward from a uint8 BGR batch [B,H,W,3] on the device: mean subtraction, zero padding and channel packing run
         in one kernel in place of the host-side preprocess_image / compute_inputs (4x less host->device traffic)."""
         if sizes_hw is None:
             sizes_hw = [(self.H, self.W)] * self.B
+        cur = self._enter()
         x4 = self.acts["input4"]
         if self.stem3:
             ops.preprocess_caffe_u8_padded(self.ctx, images_u8, sizes_hw, x4.t, *self.stem_frame)
@@ -802,13 +840,16 @@ class Engine(object):
             self.forward(None)
         finally:
             skip.fn = fn
+        self._leave(cur)
 
     def export_outputs(self):
         """Keras prediction-model outputs (models/retinanet.py:302-335): [boxes3D, cls probs, mask probs]."""
         ctx = self.ctx
+        cur = self._enter()
         ops.export_head(ctx, self.pyr.rowspace(), self.A, 16, self.reg_out.t, False, self.out_box)
         ops.export_head(ctx, self.pyr.rowspace(), self.A, self.C, self.cls_out.t, True, self.out_cls)
         ops.export_head(ctx, self.P3.rowspace(), 1, self.C, self.mask_out.t, True, self.out_mask)
+        self._leave(cur)
         return self.out_box, self.out_cls, self.out_mask
 
     def anchors_device_f32(self):
@@ -822,28 +863,37 @@ class Engine(object):
         """-> (boxes3D (B,N,16), scores (B,N,C), mask (B,HW/64,C)) device tensors."""
         self.forward(x)
         reg, cls, mask = self.export_outputs()
-        boxes3d = ops.box3d_decode(self.ctx, self.anchors_device_f32(), reg)
+        cur = self._enter()
+        with torch.cuda.stream(self.streams[0]):  # (the result tensor is allocated for the stream that writes it)
+            boxes3d = ops.box3d_decode(self.ctx, self.anchors_device_f32(), reg)
+        self._leave(cur)
         return boxes3d, cls, mask
 
     def set_targets(self, y_box, y_cls, y_mask):
-        self.y_box.copy_(y_box)
-        self.y_cls.copy_(y_cls)
-        self.y_mask.copy_(y_mask)
+        cur = self._enter()
+        with torch.cuda.stream(self.streams[0]):
+            self.y_box.copy_(y_box)
+            self.y_cls.copy_(y_cls)
+            self.y_mask.copy_(y_mask)
+        self._leave(cur)
 
     def loss_and_backward(self):
         """Counts -> (DP: global counts) -> fused loss fwd+bwd -> backward plan.  Leaves gradients in params.grad."""
         ctx, P = self.ctx, self.params
-        P.grad.zero_()
-        self.counts.zero_()
-        self.loss_sums.zero_()
-        ops.count_positives(ctx, self.y_box, self.y_cls, self.y_mask, self.counts)
-        if self.grad_sync is not None:
-            self.grad_sync.reduce_counts(self.counts)
-        ops.orth_l1(ctx, self.pyr.rowspace(), self.A, self.reg_out.t, self.y_box, 0.125, 3.0, self.counts[0:1], 1.0,
+        cur = self._enter()
+        with torch.cuda.stream(self.streams[0]):
+            P.grad.zero_()
+            self.counts.zero_()
+            self.loss_sums.zero_()
+            ops.count_positives(ctx, self.y_box, self.y_cls, self.y_mask, self.counts)
+            if self.grad_sync is not None:
+                self.grad_sync.reduce_counts(self.counts)
+        (bw, bs), (ca, cg), (ma, mg) = self.loss_params["box"], self.loss_params["cls"], self.loss_params["mask"]
+        ops.orth_l1(ctx, self.pyr.rowspace(), self.A, self.reg_out.t, self.y_box, bw, bs, self.counts[0:1], 1.0,
                     self.loss_sums[0:1], self.g_reg)
-        ops.focal(ctx, self.pyr.rowspace(), self.A, self.C, self.cls_out.t, self.y_cls, 0.25, 2.0, self.counts[1:2], 1.0,
+        ops.focal(ctx, self.pyr.rowspace(), self.A, self.C, self.cls_out.t, self.y_cls, ca, cg, self.counts[1:2], 1.0,
                   self.loss_sums[1:2], self.g_cls)
-        ops.focal(ctx, self.P3.rowspace(), 1, self.C, self.mask_out.t, self.y_mask, 0.25, 2.0, self.counts[2:3], 1.0,
+        ops.focal(ctx, self.P3.rowspace(), 1, self.C, self.mask_out.t, self.y_mask, ma, mg, self.counts[2:3], 1.0,
                   self.loss_sums[2:3], self.g_mask)
         sync = self.grad_sync
         for i, op in enumerate(self.bwd_ops):
@@ -853,6 +903,7 @@ class Engine(object):
             if sync is not None:
                 sync.after_bwd_op(i, self.streams[op.lane])
         self._join(list(range(1, self.n_lanes)))
+        self._leave(cur)
 
     def refresh_planes(self, only_trainable=False):
         """Re-split the effective weights into the bf16 (hi, lo) planes of the bf16x3 kernels (one launch)."""
@@ -869,11 +920,13 @@ class Engine(object):
 
     def optimizer_step(self):
         P = self.params
+        cur = self._enter()
         self.step_count += 1
         self.opt.grad_norm(P.w_master, P.grad, P.scales, self.gnorm_sq, self.loss_sums[3:4])
         self.opt.adam_step(P.w_master, P.w_eff, P.grad, P.scales, P.m, P.v, self.gnorm_sq, self.lr, self.beta1, self.beta2,
                            self.eps, self.clipnorm, self.step_count)
         self.refresh_planes(only_trainable=True)
+        self._leave(cur)
 
     def train_step(self, x=None, targets=None):
         """One optimisation step (Keras train_on_batch): fwd + losses + bwd + clipnorm-Adam.  Returns nothing;

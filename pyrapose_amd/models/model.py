@@ -49,7 +49,9 @@ class PyraPoseModel(object):
         self.output_names = list(OUTPUT_NAMES)
         na = self.anchor_params.num_anchors()
         self._weights = weights if weights is not None else arch.init_weights(self.num_classes, seed, backbone, pyramid, na)
-        self._engine = None
+        self._engine = None          # the plan that holds the freshest weights (the last one used)
+        self._engines = OrderedDict()  # (B, H, W, train) -> Engine
+        self._weights_version = 0    # bumped by every optimisation step / load_weights
         self._loss = None
         self._optimizer = None
         self.freeze_backbone = freeze_backbone
@@ -57,23 +59,81 @@ class PyraPoseModel(object):
         self.layers = [_LayerHandle(s.name, self) for s in arch.all_specs(self.num_classes, backbone, pyramid, na)]
 
     # ---- engine management ---------------------------------------------------------------------
+    MAX_ENGINES = 4  # plans kept alive (one per (batch, height, width, train) key), least recently used first out
+
+    def _loss_params(self):
+        l = self._loss or {}
+        out = {}
+        if "3Dbox" in l:
+            out["box"] = (l["3Dbox"].weight, l["3Dbox"].sigma)
+        for key, name in (("cls", "cls"), ("mask", "mask")):
+            if name in l:
+                out[key] = (l[name].alpha, l[name].gamma)
+        return out
+
     def _get_engine(self, B, H, W, train):
-        e = self._engine
-        if e is not None and (e.B, e.H, e.W) == (B, H, W) and (e.train or not train):
-            return e
-        if e is not None:
-            self._weights = e.params.export()
-        lr = self._optimizer.lr if self._optimizer else 1e-5
-        clip = self._optimizer.clipnorm if self._optimizer else 0.001
-        self._engine = Engine(default_context(), self.num_classes, B, H, W, self.backbone_name, self._weights,
-                              train=train, lr=lr, clipnorm=clip, freeze_backbone=self.freeze_backbone, pyramid=self.pyramid,
-                              anchor_params=self.anchor_params)
-        if self._optimizer is not None:
-            self._engine.beta1, self._engine.beta2, self._engine.eps = self._optimizer.beta_1, self._optimizer.beta_2, self._optimizer.epsilon
-        if train and int(os.environ.get("WORLD_SIZE", "1")) > 1:
-            from ..parallel import DataParallel
-            DataParallel(self._engine)
-        return self._engine
+        """The launch plan for one (batch, height, width, train) key.  Plans are CACHED: the training engine -- which owns the
+        Adam moments and the step count -- survives a predict_on_batch at another batch size (the epoch-end evaluation of
+        callbacks/eval.py through RedirectModel), and the weights travel between plans device-to-device.  When the training
+        shape itself changes, the moments and the step count move to the new plan as well."""
+        key = (int(B), int(H), int(W), bool(train))
+        engines = self._engines
+        e = engines.get(key)
+        if e is None and not train:
+            e = engines.get((key[0], key[1], key[2], True))  # a training plan of the same shape can predict
+        cur = self._engine
+        if e is None:
+            lr = self._optimizer.lr if self._optimizer else 1e-5
+            clip = self._optimizer.clipnorm if self._optimizer else 0.001
+            world = 1
+            if train:
+                from ..parallel import ensure_process_group
+                world = ensure_process_group()
+            e = Engine(default_context(), self.num_classes, B, H, W, self.backbone_name, self._weights,
+                       train=train, lr=lr, clipnorm=clip, freeze_backbone=self.freeze_backbone, pyramid=self.pyramid,
+                       anchor_params=self.anchor_params, loss_params=self._loss_params())
+            if self._optimizer is not None:
+                e.beta1, e.beta2, e.eps = self._optimizer.beta_1, self._optimizer.beta_2, self._optimizer.epsilon
+            if train and world > 1:
+                from ..parallel import DataParallel
+                DataParallel(e)
+            if train:  # a new training shape inherits the optimizer state of the previous training plan
+                prev = next((o for k, o in reversed(list(engines.items())) if k[3]), None)
+                if prev is not None:
+                    e.params.m.copy_(prev.params.m)
+                    e.params.v.copy_(prev.params.v)
+                    e.step_count = prev.step_count
+            e._weights_version = -1
+            engines[key] = e
+            while len(engines) > self.MAX_ENGINES:
+                for k in list(engines):
+                    if engines[k] is not e and engines[k] is not cur:
+                        engines.pop(k).close()
+                        break
+                else:
+                    break
+        else:
+            k_found = next(k for k, o in engines.items() if o is e)
+            engines.move_to_end(k_found)
+        if cur is not None and cur is not e and e._weights_version != self._weights_version:
+            # the freshest weights live in `cur`: hand them over on the device (master + BN-folded copies + BN scales)
+            torch.cuda.synchronize()
+            e.params.w_master.copy_(cur.params.w_master)
+            e.params.w_eff.copy_(cur.params.w_eff)
+            e.params.scales.copy_(cur.params.scales)
+            e.params._bn_raw = getattr(cur.params, "_bn_raw", {})
+            e.refresh_planes()
+        e._weights_version = self._weights_version
+        self._engine = e
+        return e
+
+    def _drop_engines(self):
+        if self._engine is not None:
+            self._weights = self._engine.params.export()
+        for e in self._engines.values():
+            e.close()
+        self._engines.clear()
+        self._engine = None
 
     # ---- Keras surface -----------------------------------------------------------------------------
     def get_layer(self, name):
@@ -96,9 +156,7 @@ class PyraPoseModel(object):
                 raise ValueError("compile: output '%s' needs pyrapose_amd.losses.%s() (bin/train.py:95-102)" % (k, kind))
         self._loss = loss
         self._optimizer = optimizer or optimizers.Adam(lr=1e-5, clipnorm=0.001)
-        if self._engine is not None:
-            self._weights = self._engine.params.export()
-            self._engine = None
+        self._drop_engines()  # a (re)compiled model starts with fresh optimizer state, like Keras
 
     def get_weights_dict(self):
         return self._engine.params.export() if self._engine is not None else self._weights
@@ -124,9 +182,11 @@ class PyraPoseModel(object):
                 raise ValueError("load_weights: shape mismatch for %s: %s vs %s" % (k, W[k].shape, data[k].shape))
             W[k] = data[k].astype(np.float32)
         self._weights = W
+        self._weights_version += 1
         if self._engine is not None:
             self._engine.params.load(W)
             self._engine.refresh_planes()
+            self._engine._weights_version = self._weights_version
 
     def save_weights(self, filepath):
         """numpy container, written under exactly the given name (the reference's snapshot names end in '.h5')."""
@@ -153,6 +213,8 @@ class PyraPoseModel(object):
         eng = self._get_engine(B, H, W, train=True)
         ys = [t if torch.is_tensor(t) else torch.from_numpy(np.ascontiguousarray(t, np.float32)).cuda() for t in y]
         eng.train_step(xt, ys)
+        self._weights_version += 1
+        eng._weights_version = self._weights_version
         l = eng.losses()
         return [l["total"], l["3Dbox"], l["cls"], l["mask"]]
 
@@ -161,6 +223,12 @@ class PyraPoseModel(object):
         """bin/train.py:381-390.  The generator follows the Sequence contract of preprocessing/generator.py:384-398."""
         callbacks = callbacks or []
         steps = int(steps_per_epoch or len(generator))
+        # data parallel (WORLD_SIZE ranks, one per GPU): rank r takes batches r, r + world, ... of the generator's order, so an
+        # epoch still visits every batch once and a step consumes `world` of them (the global batch)
+        world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+        if world > 1:
+            steps = -(-steps // world)
+        pick = (lambda i: generator[(i * world + rank) % len(generator)])
         history = {"loss": []}
         for cb in callbacks:
             if hasattr(cb, "set_model"):
@@ -174,12 +242,14 @@ class PyraPoseModel(object):
                 # thread (pyrapose_amd/prefetch.py); the losses stay on the device and are read when they are printed
                 from ..prefetch import DevicePrefetcher
                 acc, eng = None, None
-                feed = DevicePrefetcher(lambda i: generator[i % len(generator)], steps, depth=min(max(int(max_queue_size), 2), 4))
+                feed = DevicePrefetcher(pick, steps, depth=min(max(int(max_queue_size), 2), 4))
                 for i, (x, y) in enumerate(feed):
                     if self._loss is None:
                         raise RuntimeError("fit_generator before compile()")
                     eng = self._get_engine(x.shape[0], x.shape[1], x.shape[2], train=True)
                     eng.train_step(x, list(y))
+                    self._weights_version += 1
+                    eng._weights_version = self._weights_version
                     acc = eng.loss_sums.clone() if acc is None else acc.add_(eng.loss_sums)
                     if verbose and (i % 10 == 0 or i + 1 == steps):
                         l = eng.losses()
@@ -188,7 +258,7 @@ class PyraPoseModel(object):
                 run = float(acc.sum().cpu()) if acc is not None else 0.0
             else:
                 for i in range(steps):
-                    x, y = generator[i % len(generator)]
+                    x, y = pick(i)
                     out = self.train_on_batch(x, y)
                     run += out[0]
                     if verbose and (i % 10 == 0 or i + 1 == steps):
@@ -215,8 +285,8 @@ class PyraPoseModel(object):
 
     def set_lr(self, lr):
         self._optimizer.lr = float(lr)
-        if self._engine is not None:
-            self._engine.lr = float(lr)
+        for e in self._engines.values():
+            e.lr = float(lr)
 
 
 class PredictionModel(object):

@@ -12,8 +12,25 @@ equivalence therefore needs two exchanges per step and nothing else:
 The global-norm clip then runs redundantly on every rank on the reduced buffer (fixed-order reduction,
 so all ranks compute the same factor).  Frozen tensors (conv1, res2*) are never communicated.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def ensure_process_group(device=None):
+    """WORLD_SIZE > 1 (the process was started by torch.distributed.run or bench.py's own launcher) and no process group yet:
+    create the RCCL group (backend 'nccl'; PP_DIST_BACKEND=gloo for CPU / shared-card rehearsals).  Returns the world size."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("PP_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dev = torch.device("cuda", int(device if device is not None else os.environ.get("LOCAL_RANK", "0")))
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    return world
 
 
 def plan_buckets(entries, bwd_ops, bucket_bytes):
@@ -33,15 +50,16 @@ def plan_buckets(entries, bwd_ops, bucket_bytes):
             end, acc = a, 0
     if end > lo:
         cuts.append((lo, end))
+    # a bucket is complete once EVERY launch that writes into it has been enqueued: a weight-gradient launch writes the
+    # layer's kernel AND bias slots (wrange = [kernel offset, bias end)), and a cut may fall between the two
     ready = [-1] * len(cuts)
     for i, op in enumerate(bwd_ops):
         wr = getattr(op, "wrange", None)
         if wr is None:
             continue
         for bi, (a, b) in enumerate(cuts):
-            if a <= wr[0] < b:
+            if wr[0] < b and a < wr[1]:
                 ready[bi] = max(ready[bi], i)
-                break
     out = [(a, b, r) for (a, b), r in zip(cuts, ready)]
     out.sort(key=lambda t: t[2])
     return out
@@ -51,6 +69,9 @@ class DataParallel(object):
     def __init__(self, engine, group=None, bucket_bytes=32 << 20):
         self.eng, self.group = engine, group
         self.active = dist.is_initialized()
+        if not self.active and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise RuntimeError("DataParallel: WORLD_SIZE=%s but torch.distributed is not initialised -- every rank would silently train "
+                               "its own copy; call parallel.ensure_process_group() first" % os.environ["WORLD_SIZE"])
         self.world = dist.get_world_size(group) if self.active else 1
         self.buckets = plan_buckets(engine.params.entries, engine.bwd_ops, bucket_bytes)
         self.by_op = {}
@@ -87,6 +108,12 @@ class DataParallel(object):
     def finish(self):
         for (a, b) in self.by_op.get(-1, ()):  # buckets no weight-gradient op maps to (defensive)
             self._launch(a, b)
-        for w in self.works:
-            w.wait()  # orders the compute stream after the collective; no host sync
+        st = getattr(self.eng, "streams", None)
+        if self.on_gpu and st:
+            with torch.cuda.stream(st[0]):  # the optimizer runs on the engine's lane 0
+                for w in self.works:
+                    w.wait()  # orders that stream after the collective; no host sync
+        else:
+            for w in self.works:
+                w.wait()
         self.works = []

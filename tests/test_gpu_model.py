@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.parity_util import assert_grads_within, assert_rows_within, engine_relu_masks
+
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-3
@@ -84,9 +86,10 @@ def test_forward_small_vs_oracle_f64(ctx, shape, mode):
     pyr_want = np.concatenate([ref[n].permute(0, 2, 3, 1).reshape(-1, 256).numpy() for n in ("P3", "P4", "P5")])
     assert rel(eng.pyr.t.cpu().numpy(), pyr_want) < TOL
     reg_raw = eng.out_box.cpu().numpy()
-    assert rel(reg_raw, ref["3Dbox"].numpy()) < TOL
-    assert rel(cls.cpu().numpy(), ref["cls"].numpy()) < TOL
-    assert rel(mask.cpu().numpy(), ref["mask"].numpy()) < TOL
+    # the head-output bar, per row (every anchor's vector against its own magnitude: tests/parity_util.py)
+    assert_rows_within(reg_raw, ref["3Dbox"].numpy(), "3Dbox", TOL)
+    assert_rows_within(cls.cpu().numpy(), ref["cls"].numpy(), "cls", TOL)
+    assert_rows_within(mask.cpu().numpy(), ref["mask"].numpy(), "mask", TOL)
     # prediction model adds Anchors + RegressBoxes3D (models/retinanet.py:302-335)
     anc = OA.anchors_for_shape_f32((H, W))
     want_box = OA.box3d_transform_inv_f32(anc[None], reg_raw)
@@ -108,39 +111,18 @@ def test_train_step_small_vs_oracle_f64(ctx, mode):
     eng.set_targets(*tg)
     eng.forward(torch.from_numpy(x).cuda())
     eng.loss_and_backward()
-    losses_ref, g_ref, _ = MT.loss_and_grads(Wt, x, y_box, y_cls, y_mask, C, torch.float64)
+    # The loss is piecewise smooth (ReLU): the oracle differentiates the SAME piece as the engine did -- it takes the 0/1
+    # pattern of every ReLU from the engine's forward (oracle/model_torch.py:_relu) -- so a pre-activation that is zero to
+    # rounding cannot land on different sides of the kink in the two evaluations, and the comparison is tight: every
+    # gradient tensor within 1e-3 (relative L2), losses within 1e-4.
+    losses_ref, g_ref, _ = MT.loss_and_grads(Wt, x, y_box, y_cls, y_mask, C, torch.float64, relu_masks=engine_relu_masks(eng))
     P = eng.params
     eng.opt.grad_norm(P.w_master, P.grad, P.scales, eng.gnorm_sq, eng.loss_sums[3:4])
     got = eng.losses()
     for k in ("3Dbox", "cls", "mask", "l2"):
         assert abs(got[k] - losses_ref[k]) <= 1e-4 * max(abs(losses_ref[k]), 1e-3), (k, got[k], losses_ref[k])
-    # gradients w.r.t. the master weights (frozen-BN scale folded back, L2 term added like the optimizer does)
     g_eff = P.export(P.grad)
-    sc = P.scales.cpu().numpy()
-    # Tolerance note: the loss has kinks (ReLU, |.|, smooth-L1 knee, p-clip) and the targets hold few positives, so
-    # the gradient is concentrated on a few rows; one ReLU whose pre-activation is within rounding of zero flips
-    # between two evaluations and moves every tensor upstream of it by 1e-2 .. 4e-2 (measured: f32 engine vs
-    # bf16x3 engine agree to 1e-5 on every tensor down to the first flipped layer of each head, then jump;
-    # PyTorch-CPU float32 autograd of the oracle differs from its float64 run by up to 2.5e-2).  The kernels
-    # themselves are pinned at 2e-5 / 1e-4 by tests/test_gpu_conv.py.  Graph-level bar: every tensor within 8e-2
-    # and the whole gradient vector within 3e-2 in relative L2 (a wrong kernel or a missing term is O(1)).
-    worst, num, den = 0.0, 0.0, 0.0
-    for key, gr in g_ref.items():
-        layer, kind = key.split("/")
-        s = P.specs[layer]
-        g = g_eff[key].astype(np.float64)
-        if kind == "kernel":
-            if s.bn:
-                off = P.entries[key]["scale_off"]
-                g = g * sc[off: off + s.cout][None, None, None, :]
-            if s.l2:
-                g = g + 2 * s.l2 * Wt[key]
-        e = rel(g, gr.numpy())
-        worst = max(worst, e)
-        n_, d_ = float(((g - gr.numpy()) ** 2).sum()), float((gr.numpy() ** 2).sum())
-        num += n_; den += d_
-        assert np.sqrt(n_ / max(d_, 1e-300)) < 8e-2, (key, e, np.sqrt(n_ / max(d_, 1e-300)))
-    assert np.sqrt(num / den) < 3e-2, np.sqrt(num / den)
+    worst, total = assert_grads_within(eng, g_ref, Wt, 1e-3, mode)
     # global norm
     norm_ref = np.sqrt(sum(float((g.double() ** 2).sum()) for g in g_ref.values()))
     assert abs(np.sqrt(float(eng.gnorm_sq.cpu())) - norm_ref) <= 1e-4 * norm_ref
@@ -148,7 +130,7 @@ def test_train_step_small_vs_oracle_f64(ctx, mode):
     for key in g_eff:
         if MT.frozen_layer(key.split("/")[0]):
             assert not np.any(g_eff[key])
-    print("worst relative gradient error", worst, "relative L2", np.sqrt(num / den))
+    print("worst tensor", worst, "whole gradient relative L2", total)
 
 
 def test_split_capture_training_step_matches_default(ctx, monkeypatch):
@@ -251,10 +233,10 @@ def test_forward_full_size_vs_oracle(ctx, mode):
     box, cls, mask = eng.predict_on_batch(torch.from_numpy(x).cuda())
     assert box.shape == (1, 56700, 16) and cls.shape == (1, 56700, 13) and mask.shape == (1, 4800, 13)
     with torch.no_grad():
-        ref = MT.forward(Wt, x, C, torch.float32)
-    assert rel(eng.out_box.cpu().numpy(), ref["3Dbox"].numpy()) < TOL
-    assert rel(cls.cpu().numpy(), ref["cls"].numpy()) < TOL
-    assert rel(mask.cpu().numpy(), ref["mask"].numpy()) < TOL
+        ref = MT.forward(Wt, x, C, torch.float64)
+    assert_rows_within(eng.out_box.cpu().numpy(), ref["3Dbox"].numpy(), "3Dbox", TOL)
+    assert_rows_within(cls.cpu().numpy(), ref["cls"].numpy(), "cls", TOL)
+    assert_rows_within(mask.cpu().numpy(), ref["mask"].numpy(), "mask", TOL)
 
 
 def test_data_parallel_path_single_rank_nccl(ctx):
@@ -340,10 +322,10 @@ def test_forward_tless_720x540_c30_vs_oracle(ctx):
     assert eng.N == 72369 and eng.M3 == 6120
     box, cls, mask = eng.predict_on_batch(torch.from_numpy(x).cuda())
     with torch.no_grad():
-        ref = MT.forward(Wt, x, C, torch.float32)
-    assert rel(eng.out_box.cpu().numpy(), ref["3Dbox"].numpy()) < TOL
-    assert rel(cls.cpu().numpy(), ref["cls"].numpy()) < TOL
-    assert rel(mask.cpu().numpy(), ref["mask"].numpy()) < TOL
+        ref = MT.forward(Wt, x, C, torch.float64)
+    assert_rows_within(eng.out_box.cpu().numpy(), ref["3Dbox"].numpy(), "3Dbox", TOL)
+    assert_rows_within(cls.cpu().numpy(), ref["cls"].numpy(), "cls", TOL)
+    assert_rows_within(mask.cpu().numpy(), ref["mask"].numpy(), "mask", TOL)
 
 
 def test_resnet101_variant_and_ycbv_classes(ctx):
@@ -367,8 +349,8 @@ def test_resnet101_variant_and_ycbv_classes(ctx):
     eng2 = Engine(ctx, C, B, H, W, backbone="resnet101", weights=Wt, train=False)
     eng2.forward(torch.from_numpy(x).cuda())
     b2, c2, m2 = eng2.export_outputs()
-    assert rel(b2.cpu().numpy(), out["3Dbox"].detach().numpy()) < TOL
-    assert rel(c2.cpu().numpy(), out["cls"].detach().numpy()) < TOL
+    assert_rows_within(b2.cpu().numpy(), out["3Dbox"].detach().numpy(), "3Dbox", TOL)
+    assert_rows_within(c2.cpu().numpy(), out["cls"].detach().numpy(), "cls", TOL)
 
 
 def test_inference_batch_decode_and_compaction(ctx):
@@ -389,7 +371,7 @@ def test_inference_batch_decode_and_compaction(ctx):
     idx, cnt = ops.score_threshold_compact(ctx, cls, 0.5)
     with torch.no_grad():
         ref = MT.forward(Wt, x, C, torch.float64)
-    assert rel(cls.cpu().numpy(), ref["cls"].numpy()) < TOL
+    assert_rows_within(cls.cpu().numpy(), ref["cls"].numpy(), "cls", TOL)
     got_scores = cls.cpu().numpy()
     idx, cnt = idx.cpu().numpy(), cnt.cpu().numpy()
     assert cnt.sum() > 100
@@ -423,10 +405,11 @@ def test_pyramid_variants_vs_oracle_f64(ctx, pyramid, anchors):
     eng.set_targets(*[torch.from_numpy(a).cuda() for a in (y_box, y_cls, y_mask)])
     eng.forward(torch.from_numpy(x).cuda())
     reg, cls, mask = [t.cpu().numpy() for t in eng.export_outputs()]
-    losses_ref, g_ref, ref = MT.loss_and_grads(Wt, x, y_box, y_cls, y_mask, C, torch.float64, pyramid=pyramid)
-    assert rel(reg, ref["3Dbox"].detach().numpy()) < TOL
-    assert rel(cls, ref["cls"].detach().numpy()) < TOL
-    assert rel(mask, ref["mask"].detach().numpy()) < TOL
+    losses_ref, g_ref, ref = MT.loss_and_grads(Wt, x, y_box, y_cls, y_mask, C, torch.float64, pyramid=pyramid,
+                                               relu_masks=engine_relu_masks(eng))
+    assert_rows_within(reg, ref["3Dbox"].detach().numpy(), "3Dbox", TOL)
+    assert_rows_within(cls, ref["cls"].detach().numpy(), "cls", TOL)
+    assert_rows_within(mask, ref["mask"].detach().numpy(), "mask", TOL)
     # decode against the float32 anchors of the same parameters
     params = dict(sizes=ap.sizes, strides=ap.strides, ratios=ap.ratios, scales=ap.scales)
     anc = OA.anchors_for_shape_f32((H, W), pyramid_levels=levels, params=params)
@@ -438,23 +421,7 @@ def test_pyramid_variants_vs_oracle_f64(ctx, pyramid, anchors):
     got = eng.losses()
     for k in ("3Dbox", "cls", "mask", "l2"):
         assert abs(got[k] - losses_ref[k]) <= 1e-4 * max(abs(losses_ref[k]), 1e-3), (k, got[k], losses_ref[k])
-    g_eff = P.export(P.grad)
-    sc = P.scales.cpu().numpy()
-    num = den = 0.0
-    for key, gr in g_ref.items():
-        layer, kind = key.split("/")
-        s = P.specs[layer]
-        g = g_eff[key].astype(np.float64)
-        if kind == "kernel":
-            if s.bn:
-                off = P.entries[key]["scale_off"]
-                g = g * sc[off: off + s.cout][None, None, None, :]
-            if s.l2:
-                g = g + 2 * s.l2 * Wt[key]
-        n_, d_ = float(((g - gr.numpy()) ** 2).sum()), float((gr.numpy() ** 2).sum())
-        num += n_; den += d_
-        assert np.sqrt(n_ / max(d_, 1e-300)) < 8e-2, (key, np.sqrt(n_ / max(d_, 1e-300)))
-    assert np.sqrt(num / den) < 3e-2, np.sqrt(num / den)
+    assert_grads_within(eng, g_ref, Wt, 1e-3, pyramid)
 
 
 def ops_box3d(eng, reg):

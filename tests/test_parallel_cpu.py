@@ -52,6 +52,28 @@ def test_plan_buckets_covers_trainable_range_once():
     assert spans[0][0] >= entries["t1"]["offset"] + entries["t1"]["count"]
 
 
+def test_bucket_cut_between_kernel_and_bias_waits_for_the_layers_launch():
+    """A weight-gradient launch writes its layer's kernel AND bias slot.  With a bucket size that puts the cut between the two,
+    BOTH buckets must wait for that launch (the bias sits in the earlier bucket of the layout walk)."""
+    from pyrapose_amd.parallel import plan_buckets
+    # layers: (kernel, bias) pairs, 64-float aligned
+    sizes = [4096, 64, 4096, 64, 4096, 64]
+    entries, total = make_layout(sizes, frozen=set())
+    names = list(entries)
+    ops = []
+    for li in (2, 1, 0):  # backward: last layer first; one launch per layer covering [kernel offset, bias end)
+        k, b = entries[names[2 * li]], entries[names[2 * li + 1]]
+        ops.append(FakeOp((k["offset"], b["offset"] + b["count"])))
+    # walking the layout backwards, 4096 + 64 floats per layer: a bucket of exactly one kernel (16 KB) cuts at every kernel,
+    # a bucket of 64 floats cuts at every entry -> bias and kernel of a layer land in different buckets
+    buckets = plan_buckets(entries, ops, bucket_bytes=64 * 4)
+    spans = sorted((a, b) for a, b, _ in buckets)
+    assert any(a == entries[names[1]]["offset"] for a, _ in spans)  # a cut does sit at a bias entry
+    for a, b, r in buckets:
+        writers = [i for i, op in enumerate(ops) if op.wrange[0] < b and a < op.wrange[1]]
+        assert writers and r == max(writers), (a, b, r, writers)
+
+
 def _worker(rank, world, port, sizes, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
