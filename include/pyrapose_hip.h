@@ -65,6 +65,15 @@ int pp_ctx_set_split_capture(pp_ctx* ctx, void* hi, void* lo);
  * the float32 atomics between reduction splits; the one exception is an Inf / NaN operand opposite an exact zero, which the
  * dense launch turns into NaN and this one into 0).  Launches that cannot use the hint run dense.  NULL, NULL cancels. */
 int pp_row_block_list(pp_ctx* ctx, const float* x, int rows, int ld, int cols, unsigned char* flags, int* list);
+/* the same scan of a tensor stored as bf16 (hi, lo) planes ([rows][ld] each) */
+int pp_row_block_list_planes(pp_ctx* ctx, const void* x_hi, const void* x_lo, int rows, int ld, int cols, unsigned char* flags, int* list);
+/* One-shot: the NEXT pp_conv2d_nhwc_fwd_bf16x3 (residual) / pp_conv2d_nhwc_bwd_data_bf16x3 (addend, relu_src) call on this
+ * context reads those epilogue operands from bf16 (hi, lo) planes instead of float32 tensors -- the storage format of every
+ * activation and gradient a bf16x3 conv produces when its output is requested as planes only (value = hi + lo, 4 bytes per
+ * element like float32, so no conv ever converts inside its loop).  The call's ld_res / ld_add / ld_rs arguments give the
+ * row pitch of the planes; its float32 residual / addend / relu_src argument must then be NULL.  Of the ReLU source only the
+ * hi plane is read (hi > 0 <=> value > 0).  Any of the three may be NULL (add_hi and add_lo go together). */
+int pp_ctx_set_epilogue_planes(pp_ctx* ctx, const void* add_hi, const void* add_lo, const void* mask_hi);
 int pp_ctx_set_row_block_skip(pp_ctx* ctx, const unsigned char* flags, const int* list);
 const char* pp_last_error_string(pp_ctx* ctx);
 const char* pp_version(void);
@@ -171,6 +180,22 @@ int pp_add_n(pp_ctx* ctx, size_t n, const float* a, const float* b, const float*
 /* y = max(x, 0): the stand-alone Activation('relu') between P6 and the P7 conv of __create_pyramid_features
  * (models/retinanet.py:154).  Its backward is the relu_src mask of the consumer's pp_conv2d_nhwc_bwd_data*. */
 int pp_relu_fwd(pp_ctx* ctx, size_t n, const float* x, float* y);
+/* The same pointwise ops on tensors in either storage format: a view is a float32 tensor (f32) or a pair of bf16 (hi, lo)
+ * planes with the same [rows][ld] geometry (value = hi + lo); an OUTPUT view may carry both, and both are then written.
+ * Inputs that may be NULL in the float32 entry points may be NULL views (all three pointers NULL) here. */
+typedef struct pp_tview {
+  const float* f32;
+  const void* hi;
+  const void* lo;
+} pp_tview;
+int pp_add_n_v(pp_ctx* ctx, size_t n, const pp_tview* a, const pp_tview* b, const pp_tview* c, const pp_tview* out);
+int pp_relu_fwd_v(pp_ctx* ctx, size_t n, const pp_tview* x, const pp_tview* y);
+int pp_upsample_nearest_add_fwd_v(pp_ctx* ctx, int n_img, int sh, int sw, int th, int tw, int c, const pp_tview* src,
+                                  const pp_tview* other, const pp_tview* out);
+int pp_upsample_nearest_add_bwd_v(pp_ctx* ctx, int n_img, int sh, int sw, int th, int tw, int c, const pp_tview* dtarget,
+                                  const pp_tview* base, const pp_tview* dsrc);
+/* planes -> float32 (value = hi + lo), n % 4 == 0: the inverse of pp_split_planes_bf16x3 up to 2^-17 */
+int pp_merge_planes_bf16x3(pp_ctx* ctx, size_t n, const void* hi, const void* lo, float* dst);
 /* [n_img,h,w,3] -> [n_img,h,w,4] zero-padded channel (feeds conv1 as cin == 4) */
 int pp_pack_rgb_to_4(pp_ctx* ctx, size_t n_pixels, const float* x3, float* x4);
 /* utils/image.py:35-62 preprocess_image(mode='caffe') + preprocessing/generator.py:319-336 compute_inputs in one pass:

@@ -51,6 +51,11 @@ class SplitJob(C.Structure):
                 ("taps", C.c_int), ("cin", C.c_int), ("cout", C.c_int), ("ld_w", C.c_int), ("tile_begin", C.c_int), ("reserved", C.c_int)]
 
 
+class TView(C.Structure):
+    """pp_tview: a tensor as float32 or as bf16 (hi, lo) planes of the same [rows][ld] geometry"""
+    _fields_ = [("f32", C.c_void_p), ("hi", C.c_void_p), ("lo", C.c_void_p)]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -87,6 +92,13 @@ _SIGS = {
     "pp_ctx_set_split_capture": (_i, [_p, _p, _p]),
     "pp_row_block_list": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "pp_ctx_set_row_block_skip": (_i, [_p, _p, _p]),
+    "pp_row_block_list_planes": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
+    "pp_ctx_set_epilogue_planes": (_i, [_p, _p, _p, _p]),
+    "pp_add_n_v": (_i, [_p, _sz, C.POINTER(TView), C.POINTER(TView), C.POINTER(TView), C.POINTER(TView)]),
+    "pp_relu_fwd_v": (_i, [_p, _sz, C.POINTER(TView), C.POINTER(TView)]),
+    "pp_upsample_nearest_add_fwd_v": (_i, [_p, _i, _i, _i, _i, _i, _i, C.POINTER(TView), C.POINTER(TView), C.POINTER(TView)]),
+    "pp_upsample_nearest_add_bwd_v": (_i, [_p, _i, _i, _i, _i, _i, _i, C.POINTER(TView), C.POINTER(TView), C.POINTER(TView)]),
+    "pp_merge_planes_bf16x3": (_i, [_p, _sz, _p, _p, _p]),
     "pp_conv_split_weights_bf16x3_batch": (_i, [_p, _i, _p, _i]),
     "pp_conv2d_nhwc_fwd_bf16x3": (_i, [_p, C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "pp_conv2d_nhwc_bwd_data_bf16x3": (_i, [_p, C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p]),

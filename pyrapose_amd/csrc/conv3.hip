@@ -45,6 +45,44 @@ __device__ __forceinline__ void split4(const float4& v4, uint2* out_hi, uint2* o
   *out_lo = *reinterpret_cast<uint2*>(&l);
 }
 
+// ---- the PACKED plane layout ----
+// A tensor [rows][ld] (ld % 8 == 0) stored as bf16 (hi, lo) planes occupies rows * ld * 4 bytes, like float32, cut into 32-byte
+// groups of 8 consecutive channels: bytes 0..15 = the 8 hi values, bytes 16..31 = the 8 lo values (value = hi + lo, within
+// 2^-17 of the float32 that was split).  "hi" points at the buffer, "lo" 16 bytes behind it, and BOTH are addressed with the
+// float32 byte offsets of the element's group -- so a staging thread that used to fetch the two float4 of an octet fetches
+// the same 32 contiguous bytes, and 128-byte row segments stay whole (two separate planes cut every access into 64-byte
+// halves and cost 5 % on the forward launches: profiles/r02_planes_separate_vs_packed.txt).
+// index of the 8-byte half-group (4 channels) i4 = element / 4 of a plane, in uint2 units from the plane's pointer
+__device__ __forceinline__ long long pk4(long long i4) { return ((i4 >> 1) << 2) + (i4 & 1); }
+
+// four consecutive elements (element index 4 * i4) of a tensor stored as planes
+__device__ __forceinline__ float4 planes_ld4(const void* hi, const void* lo, long long i4) {
+  const long long q = pk4(i4);
+  const uint2 h = reinterpret_cast<const uint2*>(hi)[q], l = reinterpret_cast<const uint2*>(lo)[q];
+  float4 v;
+  v.x = __uint_as_float(h.x << 16) + __uint_as_float(l.x << 16);
+  v.y = __uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u);
+  v.z = __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16);
+  v.w = __uint_as_float(h.y & 0xffff0000u) + __uint_as_float(l.y & 0xffff0000u);
+  return v;
+}
+// the hi plane alone: enough for the sign / zero test of a ReLU source (bf16 keeps the f32 exponent range)
+__device__ __forceinline__ float4 hi_ld4(const void* hi, long long i4) {
+  const uint2 h = reinterpret_cast<const uint2*>(hi)[pk4(i4)];
+  return make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u), __uint_as_float(h.y << 16),
+                     __uint_as_float(h.y & 0xffff0000u));
+}
+__device__ __forceinline__ void planes_st4(void* hi, void* lo, long long i4, const float4& v) {
+  uint2 oh, ol;
+  split4(v, &oh, &ol);
+  const long long q = pk4(i4);
+  reinterpret_cast<uint2*>(hi)[q] = oh;
+  reinterpret_cast<uint2*>(lo)[q] = ol;
+}
+
+// exchange with the neighbouring lane (lane ^ 1) inside a quad: DPP quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ unsigned lane_xor1(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }
+
 // exact a / b for 0 <= a < 2^24, b >= 1 by one reciprocal multiply and a +-1 correction
 __device__ __forceinline__ int div_small(int a, int b, float rcp_b, int* rem) {
   int q = (int)((float)a * rcp_b);
@@ -81,10 +119,12 @@ __device__ __forceinline__ void epilogue3(const IgemmParams& p, floatx16 (&acc)[
   float* stage = reinterpret_cast<float*>(smem);
   const int e_c4 = tid % C4, e_r = tid / C4;
   const int co = n0 + 4 * e_c4;
+  const bool odd = (e_c4 & 1) != 0;  // lanes 2j / 2j + 1 hold channels 8j .. 8j+3 / 8j+4 .. 8j+7 of the same row
   const bool col_ok = co < ((p.Nout + 3) & ~3);
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (g_bias && col_ok) bias4 = *reinterpret_cast<const float4*>(g_bias + co);
   const int m_last = p.M - 1;
+  const bool add_pl = p.add_hi != nullptr, mask_pl = p.mask_hi != nullptr;  // (uniform) operands stored as bf16 planes
 #pragma unroll
   for (int hm = 0; hm < 2; ++hm) {
 #pragma unroll
@@ -124,8 +164,28 @@ __device__ __forceinline__ void epilogue3(const IgemmParams& p, floatx16 (&acc)[
                 const int yq = div_small(rem, p.seg[0].OW, __frcp_rn((float)p.seg[0].OW), &xq);
                 mo[g] = (n * p.sc_H + 2 * yq + p.sc_cy) * p.sc_W + 2 * xq + p.sc_cx;
               }
-              if (has_add) ad[g] = *reinterpret_cast<const float4*>(g_addend + (long long)mo[g] * p.ld_add + co);
-              if (has_mask) mk[g] = *reinterpret_cast<const float4*>(g_mask + (long long)mo[g] * p.ld_mask + co);
+              if (has_add) {
+                if (add_pl) {
+                  // packed planes, 16 bytes per lane: the even lane of a pair fetches the group's hi half, the odd lane its lo half
+                  // (8-byte loads run at 0.5-0.7 of the 16-byte rate: the HBM-bound 1x1 launches were 6-25 % slower with them)
+                  const long long grp = ((long long)mo[g] * p.ld_add + (co & ~7)) >> 3;
+                  const uint4 q = reinterpret_cast<const uint4*>(p.add_hi)[2 * grp + (odd ? 1 : 0)];
+                  ad[g] = *reinterpret_cast<const float4*>(&q);  // raw halves: combined after the exchange below
+                } else {
+                  ad[g] = *reinterpret_cast<const float4*>(g_addend + (long long)mo[g] * p.ld_add + co);
+                }
+              }
+              if (has_mask) {
+                if (mask_pl) {
+                  // the hi half of the group alone (hi > 0 <=> value > 0): the even lane fetches it for the pair
+                  const long long grp = ((long long)mo[g] * p.ld_mask + (co & ~7)) >> 3;
+                  uint4 q = make_uint4(0u, 0u, 0u, 0u);
+                  if (!odd) q = reinterpret_cast<const uint4*>(p.mask_hi)[2 * grp];
+                  mk[g] = *reinterpret_cast<const float4*>(&q);
+                } else {
+                  mk[g] = *reinterpret_cast<const float4*>(g_mask + (long long)mo[g] * p.ld_mask + co);
+                }
+              }
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
@@ -137,6 +197,25 @@ __device__ __forceinline__ void epilogue3(const IgemmParams& p, floatx16 (&acc)[
               }
               float4 v = *reinterpret_cast<const float4*>(stage + row * BN + 4 * e_c4);
               v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+              if (has_add && add_pl) {
+                // even lane holds hi[0..7], odd lane lo[0..7] of the pair's 8 channels: the even lane needs lo[0..3] (odd's first
+                // half), the odd lane hi[4..7] (even's second half)
+                const uint4 q = *reinterpret_cast<const uint4*>(&ad[g]);
+                const unsigned sx = odd ? q.x : q.z, sy = odd ? q.y : q.w;
+                const unsigned rx = lane_xor1(sx), ry = lane_xor1(sy);
+                const unsigned hx = odd ? rx : q.x, hy = odd ? ry : q.y, lx = odd ? q.z : rx, ly = odd ? q.w : ry;
+                ad[g].x = __uint_as_float(hx << 16) + __uint_as_float(lx << 16);
+                ad[g].y = __uint_as_float(hx & 0xffff0000u) + __uint_as_float(lx & 0xffff0000u);
+                ad[g].z = __uint_as_float(hy << 16) + __uint_as_float(ly << 16);
+                ad[g].w = __uint_as_float(hy & 0xffff0000u) + __uint_as_float(ly & 0xffff0000u);
+              }
+              if (has_mask && mask_pl) {
+                const uint4 q = *reinterpret_cast<const uint4*>(&mk[g]);
+                const unsigned rx = lane_xor1(q.z), ry = lane_xor1(q.w);  // the even lane's second half
+                const unsigned hx = odd ? rx : q.x, hy = odd ? ry : q.y;
+                mk[g] = make_float4(__uint_as_float(hx << 16), __uint_as_float(hx & 0xffff0000u), __uint_as_float(hy << 16),
+                                    __uint_as_float(hy & 0xffff0000u));
+              }
               if (has_add) { v.x += ad[g].x; v.y += ad[g].y; v.z += ad[g].z; v.w += ad[g].w; }
               if (has_mask) {
                 v.x = mk[g].x > 0.f ? v.x : 0.f; v.y = mk[g].y > 0.f ? v.y : 0.f;
@@ -147,20 +226,28 @@ __device__ __forceinline__ void epilogue3(const IgemmParams& p, floatx16 (&acc)[
               const int trow = hm * 32 * TM + a0 * 32 + row;
               if (m <= m_last && (!XR || (trow >= 1 && trow <= 64 * TM - 2))) {
                 if (!OP || g_out != nullptr) *reinterpret_cast<float4*>(g_out + (long long)mo[g] * p.ld_out + co) = v;
-                if (OP) {  // the consumer convs read their operand pre-split: split once here instead of per tile
-                  uint2 oh, ol;
-                  split4(v, &oh, &ol);
-                  const long long o4 = ((long long)mo[g] * p.ld_out + co) >> 2;
-                  g_ohi[o4] = oh;
-                  g_olo[o4] = ol;
+              }
+              if (OP) {
+                // the output as packed planes: lanes 2j / 2j + 1 hold channels 8j .. 8j+3 / 8j+4 .. 8j+7 of the same row; they swap
+                // halves so that the even lane stores the group's 16 hi bytes and the odd lane its 16 lo bytes (one 16-byte
+                // store per lane, like the float32 tile; Nout % 8 == 0 is host-checked, so both lanes of a pair are in range)
+                uint2 oh, ol;
+                split4(v, &oh, &ol);
+                const unsigned sx = odd ? oh.x : ol.x, sy = odd ? oh.y : ol.y;
+                const unsigned rx = lane_xor1(sx), ry = lane_xor1(sy);
+                const uint4 o16 = odd ? make_uint4(rx, ry, ol.x, ol.y) : make_uint4(oh.x, oh.y, rx, ry);
+                if (m <= m_last && (!XR || (trow >= 1 && trow <= 64 * TM - 2))) {
+                  const long long grp = ((long long)mo[g] * p.ld_out + (co & ~7)) >> 3;  // 32-byte group
+                  reinterpret_cast<uint4*>(g_ohi)[2 * grp + (odd ? 1 : 0)] = o16;
                 }
               }
             }
           }
         };
-        if (g_addend != nullptr && g_mask != nullptr) sweep(std::true_type{}, std::true_type{});
-        else if (g_addend != nullptr) sweep(std::true_type{}, std::false_type{});
-        else if (g_mask != nullptr) sweep(std::false_type{}, std::true_type{});
+        const bool any_add = g_addend != nullptr || add_pl, any_mask = g_mask != nullptr || mask_pl;
+        if (any_add && any_mask) sweep(std::true_type{}, std::true_type{});
+        else if (any_add) sweep(std::true_type{}, std::false_type{});
+        else if (any_mask) sweep(std::false_type{}, std::true_type{});
         else sweep(std::false_type{}, std::false_type{});
       }
     }
@@ -212,7 +299,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
     for (int i = 0; i < TM; ++i) {
       if (AP) {
         if (a_ok[i]) {
-          const long long o8 = ((a_off[i] + red0) >> 3) + oct;
+          const long long o8 = 2 * (((a_off[i] + red0) >> 3) + oct);  // packed planes: 32-byte groups
           rah[i] = g_ahi[o8];
           ral[i] = g_alo[o8];
         } else {
@@ -381,7 +468,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
     float* __restrict__ g_ws, const int* __restrict__ g_rl = nullptr) {
   constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, NO = BK / 8;
   constexpr int SMEM_U4 = 2 * NO * (BM + BN);
-  constexpr int ES = AP ? 2 : 4;  // bytes per gathered element
+  constexpr int ES = 4;  // bytes per gathered element: f32, or packed planes (hi at the group's offset, lo 16 bytes behind = rs_a1)
   __shared__ __attribute__((aligned(16))) uint4 smem[SMEM_U4];
   uint4* Ahi = smem;
   uint4* Alo = Ahi + NO * BM;
@@ -416,7 +503,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
   const int s_begin = (int)((long long)all_steps * split / splits), s_end = (int)((long long)all_steps * (split + 1) / splits);
 
   const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_a0), 0, a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(AP ? g_a1 : g_a0), 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(AP ? g_a1 : g_a0), 0, AP ? a_bytes - 16 : a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_whi), 0, w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_wlo), 0, w_bytes, 0x00020000);
 
@@ -605,12 +692,18 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
 // pp_split_planes_bf16x3): for the centre kernel row (dy = 0: the staged rows are the tile's own rows; the BM - 2 inner
 // rows of all tiles cover every row once) the workgroups store the registers they have just converted, the output-channel
 // tiles of one row tile taking turns over the channel chunks.  The weight-gradient launch of the same layer then reads both operands pre-split (pp_ctx_set_split_capture).
-template <int TM, int TN, bool CAP>
+// AP: the gathered operand is stored as bf16 (hi, lo) planes (g_a = hi, g_a1 = lo; ld_src % 8 == 0): the staging threads move
+// 16 B of each plane per row and chunk -- the same bytes as the two f32 quads -- and nothing is converted in the loop.
+// OP: the output tile is written as planes (g_ohi / g_olo; also as f32 when g_out != NULL).
+template <int TM, int TN, bool CAP, bool AP = false, bool OP = false>
 __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3x_kernel(
-    const IgemmParams p, const void* __restrict__ g_a, unsigned a_bytes, const void* __restrict__ g_whi, const void* __restrict__ g_wlo,
-    unsigned w_bytes, const float* __restrict__ g_bias, const float* __restrict__ g_addend, const float* __restrict__ g_mask,
-    float* __restrict__ g_out, int w_rows, int w_ld8, int splits, float* __restrict__ g_ws, void* __restrict__ g_chi,
-    void* __restrict__ g_clo, const unsigned char* __restrict__ g_flags, int skip_halo) {
+    const IgemmParams p, const void* __restrict__ g_a, const void* __restrict__ g_a1, unsigned a_bytes, const void* __restrict__ g_whi,
+    const void* __restrict__ g_wlo, unsigned w_bytes, const float* __restrict__ g_bias, const float* __restrict__ g_addend,
+    const float* __restrict__ g_mask, float* __restrict__ g_out, uint2* __restrict__ g_ohi, uint2* __restrict__ g_olo, int w_rows, int w_ld8,
+    int splits, float* __restrict__ g_ws, void* __restrict__ g_chi, void* __restrict__ g_clo, const unsigned char* __restrict__ g_flags,
+    int skip_halo) {
+  static_assert(!(CAP && AP), "split capture is for f32 operands");
+  constexpr int ES = 4;  // bytes per gathered element: f32, or packed planes (hi at the group's offset, lo 16 bytes behind = rs_a1)
   constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, NO = BK / 8;
   constexpr int AP1 = NO * BM + 1;  // plane size: the tile + one all-zero slot that padded taps read instead of their row
   constexpr int SMEM_U4 = 2 * AP1 + 2 * NO * BN;
@@ -645,6 +738,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3x_kernel(
   }
 
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_a), 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(AP ? g_a1 : g_a), 0, AP ? a_bytes - 16 : a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_whi), 0, w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_wlo), 0, w_bytes, 0x00020000);
 
@@ -656,11 +750,11 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3x_kernel(
     const RowPos r = decode_row(p, q < 0 ? 0 : q);
     const bool ok = q >= 0 && r.ok;
     const int x = r.xbase - p.off_x;  // dx = 0 <=> the output cell's own column
-    s_base[i] = ((r.rowbase + r.ybase * r.SW + x) * p.ld_src + 8 * oct) * 4;
+    s_base[i] = ((r.rowbase + r.ybase * r.SW + x) * p.ld_src + 8 * oct) * ES;
     int v = 0;
     for (int ty = 0; ty < p.kh; ++ty)
       if (ok && (unsigned)(r.ybase + ty * p.tsign) < (unsigned)r.SH) v |= 1 << ty;
-    s_pitch[i] = (p.tsign * r.SW * p.ld_src * 4) | v;  // ld_src % 4 == 0 -> the pitch is a multiple of 16
+    s_pitch[i] = (p.tsign * r.SW * p.ld_src * ES) | v;  // ld_src % 4 == 0 -> the pitch is a multiple of 16
   }
   // fragment rows of this lane: wm * 32 * TM + a * 32 + il -> validity bit per tap (9 bits each, two rows per register)
   unsigned f_valid = 0;
@@ -693,11 +787,16 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3x_kernel(
   auto load_a = [&]() {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      int vo = s_base[i] + __mul24(ty, s_pitch[i] & ~15) + chunk * (BK * 4);
+      int vo = s_base[i] + __mul24(ty, s_pitch[i] & ~15) + chunk * (BK * ES);
       vo = ((s_pitch[i] >> ty) & 1) ? vo : PP_BUF_OOB;
-      const uint4 q0 = buf_load16(rs_a, vo, 0), q1 = buf_load16(rs_a, vo + 16, 0);
-      ra[i][0] = *reinterpret_cast<const float4*>(&q0);
-      ra[i][1] = *reinterpret_cast<const float4*>(&q1);
+      if (AP) {
+        rah[i] = buf_load16(rs_a, vo, 0);
+        ral[i] = buf_load16(rs_a1, vo, 0);
+      } else {
+        const uint4 q0 = buf_load16(rs_a, vo, 0), q1 = buf_load16(rs_a, vo + 16, 0);
+        ra[i][0] = *reinterpret_cast<const float4*>(&q0);
+        ra[i][1] = *reinterpret_cast<const float4*>(&q1);
+      }
     }
   };
   auto load_b = [&](int tx) {
@@ -709,8 +808,10 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3x_kernel(
     }
   };
   auto split_a = [&]() {
+    if (!AP) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) split8(ra[i][0], ra[i][1], &rah[i], &ral[i]);
+      for (int i = 0; i < TM; ++i) split8(ra[i][0], ra[i][1], &rah[i], &ral[i]);
+    }
   };
   auto store_a = [&]() {
 #pragma unroll
@@ -724,15 +825,15 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3x_kernel(
   const int ty_c = -p.off_y * p.tsign;  // kernel row with dy = 0
   auto capture = [&]() {
     if constexpr (CAP) {
-      const __amdgpu_buffer_rsrc_t rs_ch = __builtin_amdgcn_make_buffer_rsrc(g_chi, 0, a_bytes >> 1, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rs_cl = __builtin_amdgcn_make_buffer_rsrc(g_clo, 0, a_bytes >> 1, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_ch = __builtin_amdgcn_make_buffer_rsrc(g_chi, 0, a_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_cl = __builtin_amdgcn_make_buffer_rsrc(g_clo, 0, a_bytes - 16, 0x00020000);
       if (ty == ty_c && chunk % p.n_tiles_n == tile_n) {  // uniform: the output-channel tiles of a row tile take turns
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const int row = r0 + 64 * i;
           const int vo = s_base[i] + __mul24(ty, s_pitch[i] & ~15) + chunk * (BK * 4);
           const bool ok = ((s_pitch[i] >> ty) & 1) && row >= 1 && row <= BM - 2;
-          const int co = ok ? (vo >> 1) : PP_BUF_OOB;
+          const int co = ok ? vo : PP_BUF_OOB;  // packed planes: the f32 byte offset of the group
           buf_store16(rs_ch, rah[i], co);
           buf_store16(rs_cl, ral[i], co);
         }
@@ -869,12 +970,35 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3x_kernel(
       }
     return;
   }
-  epilogue3<TM, TN, false, 4, false, true>(p, acc, smem, m0, n0, tid, wm, wn, il, h, g_bias, g_addend, g_mask, g_out, nullptr, nullptr);
+  epilogue3<TM, TN, OP, 4, false, true>(p, acc, smem, m0, n0, tid, wm, wn, il, h, g_bias, g_addend, g_mask, g_out, g_ohi, g_olo);
+}
+
+// epilogue arithmetic of the pointwise finishing kernels: v (+ addend) (masked by the ReLU source) (ReLU) -> f32 and / or planes;
+// mo = row of the addend / mask / output tensors, co = first of four columns
+__device__ __forceinline__ void finish4(const IgemmParams& p, float4 v, long long mo, int co, bool with_addend, const float* __restrict__ g_addend,
+                                        const float* __restrict__ g_mask, float* __restrict__ g_out, void* __restrict__ g_ohi,
+                                        void* __restrict__ g_olo) {
+  if (with_addend) {
+    if (p.add_hi) {
+      const float4 a = planes_ld4(p.add_hi, p.add_lo, (mo * p.ld_add + co) >> 2);
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    } else if (g_addend) {
+      const float4 a = *reinterpret_cast<const float4*>(g_addend + mo * p.ld_add + co);
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+  }
+  if (p.mask_hi || g_mask) {
+    const float4 k = p.mask_hi ? hi_ld4(p.mask_hi, (mo * p.ld_mask + co) >> 2) : *reinterpret_cast<const float4*>(g_mask + mo * p.ld_mask + co);
+    v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+  }
+  if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  if (g_out) *reinterpret_cast<float4*>(g_out + mo * p.ld_out + co) = v;
+  if (g_ohi) planes_st4(g_ohi, g_olo, (mo * p.ld_out + co) >> 2, v);
 }
 
 // parity class without taps (e.g. the odd cells of a 1x1 stride-2 conv): dx = mask?(addend or 0) at the class rows
 __global__ void class_fill_kernel(const IgemmParams p, const float* __restrict__ g_addend, const float* __restrict__ g_mask,
-                                  float* __restrict__ g_out) {
+                                  float* __restrict__ g_out, void* __restrict__ g_ohi, void* __restrict__ g_olo) {
   const int n4 = (p.Nout + 3) >> 2;
   const long long total = (long long)p.M * n4;
   const int hw = p.seg[0].OH * p.seg[0].OW;
@@ -882,19 +1006,14 @@ __global__ void class_fill_kernel(const IgemmParams p, const float* __restrict__
     const int m = (int)(i / n4), co = 4 * (int)(i - (long long)m * n4);
     const int n = m / hw, rem = m - n * hw, yq = rem / p.seg[0].OW, xq = rem - yq * p.seg[0].OW;
     const long long mo = (long long)(n * p.sc_H + 2 * yq + p.sc_cy) * p.sc_W + 2 * xq + p.sc_cx;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g_addend) v = *reinterpret_cast<const float4*>(g_addend + mo * p.ld_add + co);
-    if (g_mask) {
-      const float4 k = *reinterpret_cast<const float4*>(g_mask + mo * p.ld_mask + co);
-      v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
-    }
-    *reinterpret_cast<float4*>(g_out + mo * p.ld_out + co) = v;
+    finish4(p, make_float4(0.f, 0.f, 0.f, 0.f), mo, co, true, g_addend, g_mask, g_out, g_ohi, g_olo);
   }
 }
 
 // out = relu?(mask?(sum_s ws[s] + bias + addend)) over [M][ceil4(Nout)]
 __global__ void splitk_finish_kernel(const IgemmParams p, int splits, const float* __restrict__ ws, const float* __restrict__ g_bias,
-                                     const float* __restrict__ g_addend, const float* __restrict__ g_mask, float* __restrict__ g_out) {
+                                     const float* __restrict__ g_addend, const float* __restrict__ g_mask, float* __restrict__ g_out,
+                                     void* __restrict__ g_ohi, void* __restrict__ g_olo) {
   const int n4 = (p.Nout + 3) >> 2;
   const long long total = (long long)p.M * n4, slice = (long long)p.M * p.ld_out;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -906,16 +1025,7 @@ __global__ void splitk_finish_kernel(const IgemmParams p, int splits, const floa
       v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
     }
     if (g_bias) { const float4 b = *reinterpret_cast<const float4*>(g_bias + co); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-    if (g_addend) {
-      const float4 a = *reinterpret_cast<const float4*>(g_addend + (long long)m * p.ld_add + co);
-      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-    }
-    if (g_mask) {
-      const float4 k = *reinterpret_cast<const float4*>(g_mask + (long long)m * p.ld_mask + co);
-      v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
-    }
-    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    *reinterpret_cast<float4*>(g_out + (long long)m * p.ld_out + co) = v;
+    finish4(p, v, (long long)m, co, true, g_addend, g_mask, g_out, g_ohi, g_olo);
   }
 }
 
@@ -924,8 +1034,8 @@ __global__ void split_planes_kernel(size_t n8, const float4* __restrict__ src, u
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
     uint4 h, l;
     split8(src[2 * i], src[2 * i + 1], &h, &l);
-    hi[i] = h;
-    lo[i] = l;
+    hi[2 * i] = h;  // packed planes: group i = 32 bytes, hi then lo (lo = hi + 16 bytes)
+    lo[2 * i] = l;
   }
 }
 
@@ -938,6 +1048,22 @@ __global__ void row_block_flags_kernel(const float* __restrict__ x, int rows, in
     const int r = i / cols4, c = i - r * cols4;
     const float4 v = *reinterpret_cast<const float4*>(x + (long long)(r0 + r) * ld + 4 * c);
     any |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);  // NaN != 0: a block with a NaN is kept
+  }
+  any = __syncthreads_or(any);
+  if (threadIdx.x == 0) flags[blk] = any ? 1 : 0;
+}
+
+// the same scan of a tensor stored as bf16 (hi, lo) planes: value != 0 <=> a magnitude bit is set in hi or lo
+__global__ void row_block_flags_planes_kernel(const uint2* __restrict__ hi, const uint2* __restrict__ lo, int rows, int ld4, int cols4,
+                                              unsigned char* __restrict__ flags) {
+  const int blk = blockIdx.x, r0 = blk * 32;
+  const int nr = rows - r0 < 32 ? rows - r0 : 32;
+  int any = 0;
+  for (int i = threadIdx.x; i < nr * cols4; i += blockDim.x) {
+    const int r = i / cols4, c = i - r * cols4;
+    const long long o = pk4((long long)(r0 + r) * ld4 + c);
+    const uint2 h = hi[o], l = lo[o];
+    any |= ((h.x | h.y | l.x | l.y) & 0x7fff7fffu) != 0u;
   }
   any = __syncthreads_or(any);
   if (threadIdx.x == 0) flags[blk] = any ? 1 : 0;
@@ -979,10 +1105,24 @@ extern "C" int pp_row_block_list(pp_ctx* ctx, const float* x, int rows, int ld, 
   return PP_OK;
 }
 
+extern "C" int pp_row_block_list_planes(pp_ctx* ctx, const void* x_hi, const void* x_lo, int rows, int ld, int cols, unsigned char* flags,
+                                        int* list) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, x_hi && x_lo && flags && list && rows > 0 && cols > 0 && cols <= ld && ld % 8 == 0 && pp_is_packed(x_hi, x_lo), PP_ERR_ARG,
+               "pp_row_block_list_planes: bad tensor (ld %% 8 == 0, packed planes)");
+  const int nb = (rows + 31) / 32, cols4 = (cols + 3) / 4;
+  PP_CHECK_ARG(ctx, 4 * cols4 <= ld, PP_ERR_SHAPE, "pp_row_block_list_planes: cols rounded up to 4 exceed ld");
+  hipLaunchKernelGGL(row_block_flags_planes_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const uint2*)x_hi, (const uint2*)x_lo, rows,
+                     ld / 4, cols4, flags);
+  hipLaunchKernelGGL(row_block_compact_kernel, dim3(1), dim3(256), 0, ctx->stream, (const unsigned char*)flags, nb, list);
+  PP_CHECK_LAUNCH(ctx, "pp_row_block_list_planes");
+  return PP_OK;
+}
+
 extern "C" int pp_split_planes_bf16x3(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo) {
   PP_REQUIRE_CTX(ctx);
   PP_CHECK_ARG(ctx, src && hi && lo && n % 8 == 0, PP_ERR_ARG, "pp_split_planes_bf16x3: n must be a multiple of 8");
-  PP_CHECK_ARG(ctx, pp_is_aligned16(src) && pp_is_aligned16(hi) && pp_is_aligned16(lo), PP_ERR_ALIGN, "pp_split_planes_bf16x3: alignment");
+  PP_CHECK_ARG(ctx, pp_is_aligned16(src) && pp_is_packed(hi, lo), PP_ERR_ALIGN, "pp_split_planes_bf16x3: alignment / packed planes (lo = hi + 16 bytes)");
   if (n == 0) return PP_OK;
   size_t blocks = (n / 8 + 255) / 256;
   const size_t cap = (size_t)(ctx->n_cu > 0 ? ctx->n_cu : 256) * 8;
@@ -1079,7 +1219,8 @@ extern "C" int pp_conv_split_weights_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, 
 static bool igemm3_fast_ok(const IgemmParams& p, bool planes, int w_rows, int w_ld8) {
   // the branch-free loop needs a tap-linear gather and 31-bit byte offsets (see igemm3f_kernel)
   static const bool fast_on = []() { const char* e = getenv("PP_CONV3_FAST"); return !(e && e[0] == '0'); }();
-  const long long a_bytes = p.src_rows * (long long)p.ld_src * (planes ? 2 : 4);
+  const long long a_bytes = p.src_rows * (long long)p.ld_src * 4;  // (packed planes take the same 4 bytes per element)
+  (void)planes;
   const long long w_bytes = (long long)p.w_taps * w_rows * w_ld8 * 16;
   int max_sw = 0;
   for (int i = 0; i < p.n_seg; ++i) max_sw = p.seg[i].SW > max_sw ? p.seg[i].SW : max_sw;
@@ -1090,8 +1231,9 @@ static bool igemm3_fast_ok(const IgemmParams& p, bool planes, int w_rows, int w_
 // the tap-row-reuse kernel applies: 3-wide stride-1 "same" geometry on an f32 operand (conditions of igemm3x_kernel)
 static bool igemm3x_ok(const IgemmParams& p, bool planes_in, bool planes_out, int w_rows, int w_ld8) {
   static const bool x_on = []() { const char* e = getenv("PP_CONV3_XREUSE"); return !(e && e[0] == '0'); }();
-  bool same = x_on && igemm3_fast_ok(p, planes_in, w_rows, w_ld8) && !planes_in && !planes_out && !p.sc_on && p.kw == 3 && p.mul == 1 &&
-              p.div == 1 && p.src != nullptr && p.w_tstep == 1 && p.w_tx0 == 0;
+  bool same = x_on && igemm3_fast_ok(p, planes_in, w_rows, w_ld8) && !p.sc_on && p.kw == 3 && p.mul == 1 && p.div == 1 &&
+              (p.src != nullptr || planes_in) && (!planes_in || p.ld_src % 8 == 0) && p.w_tstep == 1 && p.w_tx0 == 0;
+  (void)planes_out;
   for (int i = 0; i < p.n_seg && same; ++i)
     same = p.seg[i].OH == p.seg[i].SH && p.seg[i].OW == p.seg[i].SW && p.seg[i].row_begin == p.seg[i].src_row_begin;
   return same;
@@ -1123,7 +1265,7 @@ __global__ void rl_dilate_kernel(const IgemmParams p, const unsigned char* __res
 
 // rows of the blocks that no non-zero reaches: dx = mask?(addend or 0)
 __global__ void rl_fill_kernel(const IgemmParams p, const unsigned char* __restrict__ live, const float* __restrict__ g_addend,
-                               const float* __restrict__ g_mask, float* __restrict__ g_out) {
+                               const float* __restrict__ g_mask, float* __restrict__ g_out, void* __restrict__ g_ohi, void* __restrict__ g_olo) {
   const int b = blockIdx.x;
   if (live[b]) return;
   const int n4 = (p.Nout + 3) >> 2;
@@ -1131,15 +1273,16 @@ __global__ void rl_fill_kernel(const IgemmParams p, const unsigned char* __restr
   for (int i = threadIdx.x; i < nr * n4; i += blockDim.x) {
     const int r = i / n4, co = 4 * (i - r * n4);
     const long long m = r0 + r;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g_addend) {  // (without an addend the row is zero whatever the mask says: nothing to read)
-      v = *reinterpret_cast<const float4*>(g_addend + m * p.ld_add + co);
-      if (g_mask) {
-        const float4 k = *reinterpret_cast<const float4*>(g_mask + m * p.ld_mask + co);
-        v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g_addend || p.add_hi) {
+      finish4(p, z, m, co, true, g_addend, g_mask, g_out, g_ohi, g_olo);
+    } else {  // (without an addend the row is zero whatever the mask says: nothing to read)
+      if (g_out) *reinterpret_cast<float4*>(g_out + m * p.ld_out + co) = z;
+      if (g_ohi) {
+        reinterpret_cast<uint2*>(g_ohi)[pk4((m * p.ld_out + co) >> 2)] = make_uint2(0u, 0u);
+        reinterpret_cast<uint2*>(g_olo)[pk4((m * p.ld_out + co) >> 2)] = make_uint2(0u, 0u);
       }
     }
-    *reinterpret_cast<float4*>(g_out + m * p.ld_out + co) = v;
   }
 }
 
@@ -1148,8 +1291,8 @@ __global__ void row_block_compact_kernel(const unsigned char* __restrict__ flags
 // the whole sparse bwd-data: dilate -> compact -> igemm3f over the listed blocks -> fill the others.  scratch: n_blocks bytes
 // + (n_blocks + 1) ints behind the caller's flags / list (pp_row_block_list documents the sizes).
 template <int TM, int TN>
-static void launch_igemm3_rowlist(hipStream_t st, IgemmParams& p, const void* whi, const void* wlo, int w_rows, int w_ld8,
-                                  const unsigned char* dy_flags, unsigned char* out_flags, int* out_list) {
+static void launch_igemm3_rowlist(hipStream_t st, IgemmParams& p, const void* ahi, const void* alo, const void* whi, const void* wlo, int w_rows,
+                                  int w_ld8, void* ohi, void* olo, const unsigned char* dy_flags, unsigned char* out_flags, int* out_list) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   const int nb = (p.M + 31) / 32;
   hipLaunchKernelGGL(rl_dilate_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, p, dy_flags, out_flags, nb);
@@ -1157,10 +1300,17 @@ static void launch_igemm3_rowlist(hipStream_t st, IgemmParams& p, const void* wh
   p.n_tiles_n = (p.Nout + BN - 1) / BN;
   const int n_tiles_m = (nb + BM / 32 - 1) / (BM / 32);
   const long long a_bytes = p.src_rows * (long long)p.ld_src * 4, w_bytes = (long long)p.w_taps * w_rows * w_ld8 * 16;
-  hipLaunchKernelGGL((igemm3f_kernel<TM, TN, false, false, false, true>), dim3((unsigned)(n_tiles_m * p.n_tiles_n)), dim3(256), 0, st, p,
-                     (const void*)p.src, nullptr, (unsigned)a_bytes, whi, wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out,
-                     (uint2*)nullptr, (uint2*)nullptr, w_rows, w_ld8, 1, (float*)nullptr, (const int*)out_list);
-  hipLaunchKernelGGL(rl_fill_kernel, dim3((unsigned)nb), dim3(256), 0, st, p, (const unsigned char*)out_flags, p.addend, p.mask_src, p.out);
+  const dim3 grid((unsigned)(n_tiles_m * p.n_tiles_n));
+  if (ahi)  // planes in, planes out (host-checked: both or neither)
+    hipLaunchKernelGGL((igemm3f_kernel<TM, TN, true, true, false, true>), grid, dim3(256), 0, st, p, ahi, alo, (unsigned)a_bytes, whi, wlo,
+                       (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)ohi, (uint2*)olo, w_rows, w_ld8, 1, (float*)nullptr,
+                       (const int*)out_list);
+  else
+    hipLaunchKernelGGL((igemm3f_kernel<TM, TN, false, false, false, true>), grid, dim3(256), 0, st, p, (const void*)p.src, nullptr,
+                       (unsigned)a_bytes, whi, wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)nullptr, (uint2*)nullptr,
+                       w_rows, w_ld8, 1, (float*)nullptr, (const int*)out_list);
+  hipLaunchKernelGGL(rl_fill_kernel, dim3((unsigned)nb), dim3(256), 0, st, p, (const unsigned char*)out_flags, p.addend, p.mask_src, p.out, ohi,
+                     olo);
 }
 
 static void split_capture_pass(hipStream_t st, const IgemmParams& p, void* chi, void* clo) {
@@ -1181,11 +1331,16 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
   const int n_tiles_m = (p.M + BM - 1) / BM;
   const dim3 grid((unsigned)(n_tiles_m * p.n_tiles_n * splits));
   const bool fast = igemm3_fast_ok(p, ahi != nullptr, w_rows, w_ld8);
-  const long long a_bytes = p.src_rows * (long long)p.ld_src * (ahi ? 2 : 4);
+  const long long a_bytes = p.src_rows * (long long)p.ld_src * 4;
   const long long w_bytes = (long long)p.w_taps * w_rows * w_ld8 * 16;
-  if (p.sc_on) {  // parity-class launch of a stride-2 bwd-data (host guarantees: fast, no planes, no split)
-    hipLaunchKernelGGL((igemm3f_kernel<TM, TN, false, false, true>), grid, dim3(256), 0, st, p, (const void*)p.src, nullptr, (unsigned)a_bytes, whi,
-                       wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)nullptr, (uint2*)nullptr, w_rows, w_ld8, 1, nullptr);
+  if (p.sc_on) {  // parity-class launch of a stride-2 bwd-data (host guarantees: fast, no split, planes on both sides or on neither)
+    if (ahi)
+      hipLaunchKernelGGL((igemm3f_kernel<TM, TN, true, true, true>), grid, dim3(256), 0, st, p, ahi, alo, (unsigned)a_bytes, whi, wlo,
+                         (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)ohi, (uint2*)olo, w_rows, w_ld8, 1, nullptr);
+    else
+      hipLaunchKernelGGL((igemm3f_kernel<TM, TN, false, false, true>), grid, dim3(256), 0, st, p, (const void*)p.src, nullptr, (unsigned)a_bytes,
+                         whi, wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)nullptr, (uint2*)nullptr, w_rows, w_ld8, 1,
+                         nullptr);
     return;
   }
   if constexpr (TM <= 2) {
@@ -1194,17 +1349,33 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
       int skip_halo = 0;
       for (int i = 0; i < p.n_seg; ++i) skip_halo = p.seg[i].SW + 1 > skip_halo ? p.seg[i].SW + 1 : skip_halo;
       const dim3 gridx((unsigned)(n_tiles_mx * p.n_tiles_n * splits));
+      // with split-K the partial sums go to the f32 scratch and splitk_finish_kernel writes the output (planes included)
+      const bool op = ohi != nullptr && splits == 1;
       if (chi)
-        hipLaunchKernelGGL((igemm3x_kernel<TM, TN, true>), gridx, dim3(256), 0, st, p, (const void*)p.src, (unsigned)a_bytes, whi, wlo,
-                           (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, w_rows, w_ld8, splits, ws, chi, clo, flags, skip_halo);
+        hipLaunchKernelGGL((igemm3x_kernel<TM, TN, true>), gridx, dim3(256), 0, st, p, (const void*)p.src, nullptr, (unsigned)a_bytes, whi, wlo,
+                           (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)nullptr, (uint2*)nullptr, w_rows, w_ld8, splits, ws,
+                           chi, clo, flags, skip_halo);
+      else if (ahi && op)
+        hipLaunchKernelGGL((igemm3x_kernel<TM, TN, false, true, true>), gridx, dim3(256), 0, st, p, ahi, alo, (unsigned)a_bytes, whi, wlo,
+                           (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)ohi, (uint2*)olo, w_rows, w_ld8, splits, ws, nullptr,
+                           nullptr, flags, skip_halo);
+      else if (ahi)
+        hipLaunchKernelGGL((igemm3x_kernel<TM, TN, false, true, false>), gridx, dim3(256), 0, st, p, ahi, alo, (unsigned)a_bytes, whi, wlo,
+                           (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)nullptr, (uint2*)nullptr, w_rows, w_ld8, splits, ws,
+                           nullptr, nullptr, flags, skip_halo);
+      else if (op)
+        hipLaunchKernelGGL((igemm3x_kernel<TM, TN, false, false, true>), gridx, dim3(256), 0, st, p, (const void*)p.src, nullptr,
+                           (unsigned)a_bytes, whi, wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)ohi, (uint2*)olo, w_rows,
+                           w_ld8, splits, ws, nullptr, nullptr, flags, skip_halo);
       else
-        hipLaunchKernelGGL((igemm3x_kernel<TM, TN, false>), gridx, dim3(256), 0, st, p, (const void*)p.src, (unsigned)a_bytes, whi, wlo,
-                           (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, w_rows, w_ld8, splits, ws, nullptr, nullptr, flags,
-                           skip_halo);
+        hipLaunchKernelGGL((igemm3x_kernel<TM, TN, false>), gridx, dim3(256), 0, st, p, (const void*)p.src, nullptr, (unsigned)a_bytes, whi, wlo,
+                           (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)nullptr, (uint2*)nullptr, w_rows, w_ld8, splits, ws,
+                           nullptr, nullptr, flags, skip_halo);
       return;
     }
   }
   if (chi) split_capture_pass(st, p, chi, clo);
+  if (splits > 1) ohi = olo = nullptr;  // partial sums -> scratch; splitk_finish_kernel writes the planes
   auto go = [&](auto ap, auto op) {
     constexpr bool AP = decltype(ap)::value, OP = decltype(op)::value;
     if (fast)
@@ -1279,7 +1450,7 @@ static void dispatch3(pp_ctx* ctx, IgemmParams& p, const void* ahi, const void* 
                       int w_ld8, void* ohi, void* olo, void* chi = nullptr, void* clo = nullptr, const unsigned char* flags = nullptr) {
   int tm, tn, splits;
   const int n_steps = p.kh * p.kw * (p.Cred / 32);
-  const bool may_split = ctx->ws != nullptr && !ohi && p.out != nullptr && !p.sc_on && igemm3_fast_ok(p, ahi != nullptr, w_rows, w_ld8);
+  const bool may_split = ctx->ws != nullptr && (ohi || p.out != nullptr) && !p.sc_on && igemm3_fast_ok(p, ahi != nullptr, w_rows, w_ld8);
   pick_tile3(ctx, p.M, p.Nout, p.ld_out, n_steps, may_split, igemm3x_ok(p, ahi != nullptr, ohi != nullptr, w_rows, w_ld8), &tm, &tn, &splits);
   if (getenv("PP_CONV_DEBUG"))
     fprintf(stderr, "igemm3 M %d N %d steps %d -> tile %dx%d splits %d (may_split %d: ws %d planes_out %d out %d)\n", p.M, p.Nout, n_steps, 64 * tm,
@@ -1296,7 +1467,7 @@ static void dispatch3(pp_ctx* ctx, IgemmParams& p, const void* ahi, const void* 
     const long long cap = (long long)(ctx->n_cu > 0 ? ctx->n_cu : 256) * 8;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p, splits, ctx->ws, p.bias, p.addend, p.mask_src,
-                       p.out);
+                       p.out, ohi, olo);
   }
 }
 
@@ -1306,13 +1477,20 @@ extern "C" int pp_conv2d_nhwc_fwd_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, con
   PP_REQUIRE_CTX(ctx);
   void *chi = ctx->cap_hi, *clo = ctx->cap_lo;  // one-shot (pp_ctx_set_split_capture)
   ctx->cap_hi = ctx->cap_lo = nullptr;
+  const void *ep_ah = ctx->ep_add_hi, *ep_al = ctx->ep_add_lo;  // one-shot (pp_ctx_set_epilogue_planes): the residual as planes
+  ctx->ep_add_hi = ctx->ep_add_lo = ctx->ep_mask_hi = nullptr;
   int rc = check_desc(ctx, d, "pp_conv2d_nhwc_fwd_bf16x3");
+  PP_CHECK_ARG(ctx, !(ep_ah && residual), PP_ERR_ARG, "pp_conv2d_nhwc_fwd_bf16x3: residual given both as f32 and as planes");
+  PP_CHECK_ARG(ctx, !ep_ah || (ld_res % 4 == 0 && ld_res >= ((d->cout + 3) & ~3)), PP_ERR_SHAPE, "pp_conv2d_nhwc_fwd_bf16x3: residual planes");
   if (rc) return rc;
-  PP_CHECK_ARG(ctx, !chi || (x && !x_hi), PP_ERR_ARG, "pp_conv2d_nhwc_fwd_bf16x3: split capture needs the f32 operand");
+  PP_CHECK_ARG(ctx, !chi || (x && !x_hi && pp_is_packed(chi, clo)), PP_ERR_ARG, "pp_conv2d_nhwc_fwd_bf16x3: split capture needs the f32 operand");
   PP_CHECK_ARG(ctx, (x || (x_hi && x_lo)) && w_hi && w_lo && (y || (y_hi && y_lo)), PP_ERR_ARG, "pp_conv2d_nhwc_fwd_bf16x3: null tensor");
   PP_CHECK_ARG(ctx, (x_hi == nullptr) == (x_lo == nullptr), PP_ERR_ARG, "pp_conv2d_nhwc_fwd_bf16x3: x_hi and x_lo go together");
   PP_CHECK_ARG(ctx, d->cin % 32 == 0 && d->ld_x % 8 == 0, PP_ERR_SHAPE, "pp_conv2d_nhwc_fwd_bf16x3: cin %d must be a multiple of 32, ld_x of 8", d->cin);
-  PP_CHECK_ARG(ctx, !x_hi || (pp_is_aligned16(x_hi) && pp_is_aligned16(x_lo)), PP_ERR_ALIGN, "pp_conv2d_nhwc_fwd_bf16x3: plane alignment");
+  PP_CHECK_ARG(ctx, pp_is_packed(x_hi, x_lo) && pp_is_packed(y_hi, y_lo) && pp_is_packed(ep_ah, ep_al), PP_ERR_ALIGN,
+               "pp_conv2d_nhwc_fwd_bf16x3: planes must be packed (lo = hi + 16 bytes, 16-byte aligned)");
+  PP_CHECK_ARG(ctx, !y_hi || (d->cout % 8 == 0 && d->ld_y % 8 == 0), PP_ERR_SHAPE, "pp_conv2d_nhwc_fwd_bf16x3: output planes need cout, ld_y %% 8 == 0");
+  PP_CHECK_ARG(ctx, !ep_ah || (ld_res % 8 == 0 && d->cout % 8 == 0), PP_ERR_SHAPE, "pp_conv2d_nhwc_fwd_bf16x3: residual planes need cout, ld_res %% 8 == 0");
   PP_CHECK_ARG(ctx, (!x || pp_is_aligned16(x)) && pp_is_aligned16(w_hi) && pp_is_aligned16(w_lo) && (!y || pp_is_aligned16(y)), PP_ERR_ALIGN,
                "pp_conv2d_nhwc_fwd_bf16x3: tensors must be 16-byte aligned");
   PP_CHECK_ARG(ctx, !residual || (ld_res % 4 == 0 && ld_res >= ((d->cout + 3) & ~3) && pp_is_aligned16(residual)), PP_ERR_SHAPE,
@@ -1321,6 +1499,7 @@ extern "C" int pp_conv2d_nhwc_fwd_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, con
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.src = x; p.out = y; p.bias = bias; p.addend = residual; p.mask_src = nullptr;
+  p.add_hi = ep_ah; p.add_lo = ep_al;
   p.ld_src = d->ld_x; p.ld_w = d->ld_w; p.ld_out = d->ld_y; p.ld_add = ld_res; p.ld_mask = 0;
   p.relu = relu;
   p.n_seg = d->in.n_seg;
@@ -1381,11 +1560,21 @@ extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d
   const bool skip_scratch_ok = skip_flags != nullptr && skip_list_in != nullptr;
   ctx->skip_flags = nullptr;
   ctx->skip_list = nullptr;
+  const void *ep_ah = ctx->ep_add_hi, *ep_al = ctx->ep_add_lo, *ep_mh = ctx->ep_mask_hi;  // one-shot (pp_ctx_set_epilogue_planes)
+  ctx->ep_add_hi = ctx->ep_add_lo = ctx->ep_mask_hi = nullptr;
   int rc = check_desc(ctx, d, "pp_conv2d_nhwc_bwd_data_bf16x3");
+  PP_CHECK_ARG(ctx, !(ep_ah && addend) && !(ep_mh && relu_src), PP_ERR_ARG,
+               "pp_conv2d_nhwc_bwd_data_bf16x3: addend / relu_src given both as f32 and as planes");
+  PP_CHECK_ARG(ctx, (!ep_ah || (ld_add >= d->cin && ld_add % 4 == 0)) && (!ep_mh || (ld_rs >= d->cin && ld_rs % 4 == 0)), PP_ERR_SHAPE,
+               "pp_conv2d_nhwc_bwd_data_bf16x3: addend / relu_src planes");
   if (rc) return rc;
-  PP_CHECK_ARG(ctx, !chi || (dy && !dy_hi), PP_ERR_ARG, "pp_conv2d_nhwc_bwd_data_bf16x3: split capture needs the f32 operand");
+  PP_CHECK_ARG(ctx, !chi || (dy && !dy_hi && pp_is_packed(chi, clo)), PP_ERR_ARG, "pp_conv2d_nhwc_bwd_data_bf16x3: split capture needs the f32 operand");
   PP_CHECK_ARG(ctx, (dy || (dy_hi && dy_lo)) && w_hi && w_lo && (dx || (dx_hi && dx_lo)), PP_ERR_ARG, "pp_conv2d_nhwc_bwd_data_bf16x3: null tensor");
   PP_CHECK_ARG(ctx, (dy_hi == nullptr) == (dy_lo == nullptr) && d->ld_y % 8 == 0, PP_ERR_ARG, "pp_conv2d_nhwc_bwd_data_bf16x3: planes / ld_y");
+  PP_CHECK_ARG(ctx, pp_is_packed(dy_hi, dy_lo) && pp_is_packed(dx_hi, dx_lo) && pp_is_packed(ep_ah, ep_al) && pp_is_aligned16(ep_mh), PP_ERR_ALIGN,
+               "pp_conv2d_nhwc_bwd_data_bf16x3: planes must be packed (lo = hi + 16 bytes, 16-byte aligned)");
+  PP_CHECK_ARG(ctx, (!dx_hi || (d->cin % 8 == 0 && d->ld_x % 8 == 0)) && (!ep_ah || ld_add % 8 == 0) && (!ep_mh || ld_rs % 8 == 0), PP_ERR_SHAPE,
+               "pp_conv2d_nhwc_bwd_data_bf16x3: planes need channel counts and leading dimensions %% 8 == 0");
   const int cred = (d->cout + 31) / 32 * 32;
   PP_CHECK_ARG(ctx, d->cin % 16 == 0 && d->ld_y >= cred && d->ld_y % 4 == 0, PP_ERR_SHAPE,
                "pp_conv2d_nhwc_bwd_data_bf16x3: dy needs ld_y >= %d (cout rounded up to 32, zero padded)", cred);
@@ -1397,6 +1586,7 @@ extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.src = dy; p.out = dx; p.bias = nullptr; p.addend = addend; p.mask_src = relu_src;
+  p.add_hi = ep_ah; p.add_lo = ep_al; p.mask_hi = ep_mh;
   p.ld_src = d->ld_y; p.ld_w = d->ld_w; p.ld_out = d->ld_x; p.ld_add = ld_add; p.ld_mask = ld_rs;
   p.relu = 0;
   p.n_seg = d->in.n_seg;
@@ -1408,7 +1598,8 @@ extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d
   PP_CHECK_ARG(ctx, (dx_hi == nullptr) == (dx_lo == nullptr) && (!dx_hi || (d->ld_x % 4 == 0 && pp_is_aligned16(dx_hi) && pp_is_aligned16(dx_lo))),
                PP_ERR_ARG, "pp_conv2d_nhwc_bwd_data_bf16x3: output planes");
   static const bool s2_classes = []() { const char* e = getenv("PP_CONV3_S2CLASSES"); return !(e && e[0] == '0'); }();
-  if (d->stride == 2 && s2_classes && dy && dx && !dx_hi && d->in.n_seg == 1) {
+  const bool all_f32 = dy && dx && !dy_hi && !dx_hi, all_planes = dy_hi && dx_hi && !dx;  // (the parity-class / row-list kernels exist for these two)
+  if (d->stride == 2 && s2_classes && (all_f32 || all_planes) && d->in.n_seg == 1) {
     // Stride-2 bwd-data as four stride-1 launches, one per parity class (cy, cx) of the input grid: input cell
     // (2y'+cy, 2x'+cx) only receives the taps ty = ty0 + 2i with ty0 = (cy + pad_t) & 1 (x alike), from output cell
     // y' + (cy + pad_t - ty0)/2 - i.  The single-launch form spends 3/4 of its MFMAs on taps that the divisibility
@@ -1433,28 +1624,28 @@ extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d
       r.seg[0].OW = (W - cx + 1) / 2;
       r.M = d->in.n_img * r.seg[0].OH * r.seg[0].OW;
       r.sc_on = 1; r.sc_H = H; r.sc_W = W; r.sc_cy = cy; r.sc_cx = cx;
-      if (r.M > 0 && r.kh > 0 && !(igemm3_fast_ok(r, false, d->cin, cred / 8) && r.M < (1 << 24))) ok = false;
+      if (r.M > 0 && r.kh > 0 && !(igemm3_fast_ok(r, all_planes, d->cin, cred / 8) && r.M < (1 << 24))) ok = false;
     }
     if (ok) {
       if (chi) split_capture_pass(ctx->stream, p, chi, clo);
       for (int c = 0; c < 4; ++c) {
         if (cls[c].M <= 0) continue;
         if (cls[c].kh > 0) {
-          dispatch3(ctx, cls[c], nullptr, nullptr, w_hi, w_lo, d->cin, cred / 8, nullptr, nullptr);
+          dispatch3(ctx, cls[c], dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8, dx_hi, dx_lo);
         } else {
           const long long total = (long long)cls[c].M * ((cls[c].Nout + 3) >> 2);
           long long blocks = (total + 255) / 256;
           const long long cap = (long long)(ctx->n_cu > 0 ? ctx->n_cu : 256) * 8;
           if (blocks > cap) blocks = cap;
-          hipLaunchKernelGGL(class_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, cls[c], addend, relu_src, dx);
+          hipLaunchKernelGGL(class_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, cls[c], addend, relu_src, dx, dx_hi, dx_lo);
         }
       }
       PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_data_bf16x3");
       return PP_OK;
     }
   }
-  if (skip_flags && skip_scratch_ok && !dy_hi && !dx_hi && dy && dx && !chi && d->stride == 1 && d->kh == 3 && d->kw == 3 && d->pad_t == 1 &&
-      d->pad_l == 1 && p.bias == nullptr && igemm3_fast_ok(p, false, d->cin, cred / 8)) {
+  if (skip_flags && skip_scratch_ok && (all_f32 || all_planes) && !chi && d->stride == 1 && d->kh == 3 && d->kw == 3 && d->pad_t == 1 &&
+      d->pad_l == 1 && p.bias == nullptr && igemm3_fast_ok(p, all_planes, d->cin, cred / 8)) {
     bool same = true;
     for (int i = 0; i < p.n_seg && same; ++i)
       same = p.seg[i].OH == p.seg[i].SH && p.seg[i].OW == p.seg[i].SW && p.seg[i].row_begin == p.seg[i].src_row_begin;
@@ -1465,13 +1656,15 @@ extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d
       const int nb = (p.M + 31) / 32;
       unsigned char* out_flags = const_cast<unsigned char*>(skip_flags) + nb;
       int* out_list = const_cast<int*>(skip_list_in) + nb + 1;
-      if (rl_mode == 22) launch_igemm3_rowlist<2, 2>(ctx->stream, p, w_hi, w_lo, d->cin, cred / 8, skip_flags, out_flags, out_list);
-      else launch_igemm3_rowlist<1, 2>(ctx->stream, p, w_hi, w_lo, d->cin, cred / 8, skip_flags, out_flags, out_list);
+      if (rl_mode == 22)
+        launch_igemm3_rowlist<2, 2>(ctx->stream, p, dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8, dx_hi, dx_lo, skip_flags, out_flags, out_list);
+      else
+        launch_igemm3_rowlist<1, 2>(ctx->stream, p, dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8, dx_hi, dx_lo, skip_flags, out_flags, out_list);
       PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_data_bf16x3");
       return PP_OK;
     }
   }
-  dispatch3(ctx, p, dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8, dx_hi, dx_lo, chi, clo, dy_hi ? nullptr : skip_flags);
+  dispatch3(ctx, p, dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8, dx_hi, dx_lo, chi, clo, skip_flags);
   PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_data_bf16x3");
   return PP_OK;
 }
@@ -1578,7 +1771,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 2 : 3) void wgrad3_kernel(con
     if (AP) {
 #pragma unroll
       for (int j = 0; j < OA; ++j) {
-        const long long o8 = (xrow >> 3) + q8 + 8 * j;
+        const long long o8 = 2 * ((xrow >> 3) + q8 + 8 * j);  // packed planes: 32-byte groups
         pah[j] = ok ? g_xhi[o8] : make_uint4(0u, 0u, 0u, 0u);
         pal[j] = ok ? g_xlo[o8] : make_uint4(0u, 0u, 0u, 0u);
       }
@@ -1586,7 +1779,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 2 : 3) void wgrad3_kernel(con
       for (int j = 0; j < OB; ++j) {
         const int c = n0 + 8 * (q8 + 8 * j);
         const bool okb = in_rng && c < p.ld_dy;
-        const long long o8 = (((long long)w.m * p.ld_dy + n0) >> 3) + q8 + 8 * j;
+        const long long o8 = 2 * ((((long long)w.m * p.ld_dy + n0) >> 3) + q8 + 8 * j);
         pbh[j] = okb ? g_dhi[o8] : make_uint4(0u, 0u, 0u, 0u);
         pbl[j] = okb ? g_dlo[o8] : make_uint4(0u, 0u, 0u, 0u);
       }
@@ -1779,7 +1972,8 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
                                                                             float* __restrict__ g_dbias, const int* __restrict__ g_list) {
   constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32;
   constexpr int PA = BM + 32, PB = BN + 32;  // LDS pitches in bf16 elements (row + 64 bytes)
-  constexpr int ES = AP ? 2 : 4;
+  constexpr int ES = 4;              // f32, or packed planes (32-byte groups of 8 channels: hi, then lo = the *1 resources)
+  constexpr int CB = AP ? 32 : 16;   // bytes between the 16-byte chunks a staging thread fetches from one resource
   __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BK * (PA + PB)];
   unsigned short* Xhi = smem;
   unsigned short* Xlo = Xhi + BK * PA;
@@ -1812,9 +2006,9 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
   }
 
   const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_x0), 0, x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(AP ? g_x1 : g_x0), 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(AP ? g_x1 : g_x0), 0, AP ? x_bytes - 16 : x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_d0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_d0), 0, d_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_d1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(AP ? g_d1 : g_d0), 0, d_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(AP ? g_d1 : g_d0), 0, AP ? d_bytes - 16 : d_bytes, 0x00020000);
 
   // staging: 8 threads per pixel row; thread q8 loads the 16-byte chunks q8 + 8*j of its row
   const int prow = tid >> 3, q8 = tid & 7;
@@ -1861,20 +2055,20 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
     const bool in_rng = m < m_end;
     const int sy = r_y * p.stride + ty - p.pad_t, sx = r_x * p.stride + tx - p.pad_l;
     const bool ok = in_rng && ((unsigned)sy < (unsigned)c_SH) && ((unsigned)sx < (unsigned)c_SW);
-    int xo = ((r_img + sy * c_SW + sx) * p.ld_src + ci0) * ES + 16 * q8;
+    int xo = ((r_img + sy * c_SW + sx) * p.ld_src + ci0) * ES + CB * q8;
     xo = ok ? xo : PP_BUF_OOB;
 #pragma unroll
     for (int j = 0; j < QA; ++j) {
-      ra[j] = buf_load16(rs_x0, xo, 128 * j);
-      if (AP) ral[j] = buf_load16(rs_x1, xo, 128 * j);
+      ra[j] = buf_load16(rs_x0, xo, 8 * CB * j);
+      if (AP) ral[j] = buf_load16(rs_x1, xo, 8 * CB * j);
     }
-    const int dyo = (m * p.ld_dy + n0) * ES + 16 * q8;
+    const int dyo = (m * p.ld_dy + n0) * ES + CB * q8;
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
       const bool okb = in_rng && (n0 + CH * (q8 + 8 * j) < p.ld_dy);
       const int o = okb ? dyo : PP_BUF_OOB;
-      rb[j] = buf_load16(rs_d0, o, 128 * j);
-      if (AP) rbl[j] = buf_load16(rs_d1, o, 128 * j);
+      rb[j] = buf_load16(rs_d0, o, 8 * CB * j);
+      if (AP) rbl[j] = buf_load16(rs_d1, o, 8 * CB * j);
     }
   };
   auto next_row = [&]() {  // m_cur += 32
@@ -2068,8 +2262,7 @@ static void launch_wgrad3(pp_ctx* ctx, Wgrad3Params& p, const float* x, const fl
   if (max_splits < 1) max_splits = 1;
   if (max_splits > 64) max_splits = 64;
   static const bool fast_on = []() { const char* e = getenv("PP_CONV3_FAST"); return !(e && e[0] == '0'); }();
-  const int es = xhi ? 2 : 4;
-  const long long x_bytes = p.src_rows * (long long)p.ld_src * es, d_bytes = (long long)p.M * p.ld_dy * es;
+  const long long x_bytes = p.src_rows * (long long)p.ld_src * 4, d_bytes = (long long)p.M * p.ld_dy * 4;  // f32 or packed planes
   int min_ow = 1 << 30, min_hw = 1 << 30;
   for (int i = 0; i < p.n_seg; ++i) {
     min_ow = p.seg[i].OW < min_ow ? p.seg[i].OW : min_ow;
@@ -2103,7 +2296,10 @@ static void launch_wgrad3(pp_ctx* ctx, Wgrad3Params& p, const float* x, const fl
   p.splits = splits;
   p.rows_per_split = rps;
   if (fast) {
-    if (xhi)
+    if (xhi && list)
+      hipLaunchKernelGGL((wgrad3f_kernel<TM, TN, true, true>), dim3((unsigned)(tiles * splits)), dim3(256), 0, ctx->stream, p, xhi, xlo,
+                         (unsigned)x_bytes, dhi, dlo, (unsigned)d_bytes, dw, dbias, list);
+    else if (xhi)
       hipLaunchKernelGGL((wgrad3f_kernel<TM, TN, true, false>), dim3((unsigned)(tiles * splits)), dim3(256), 0, ctx->stream, p, xhi, xlo,
                          (unsigned)x_bytes, dhi, dlo, (unsigned)d_bytes, dw, dbias, (const int*)nullptr);
     else if (list)
@@ -2132,6 +2328,8 @@ extern "C" int pp_conv2d_nhwc_bwd_weight_bf16x3(pp_ctx* ctx, const pp_conv_desc*
   PP_CHECK_ARG(ctx, ((x && dy) || planes) && dw, PP_ERR_ARG, "pp_conv2d_nhwc_bwd_weight_bf16x3: null tensor");
   PP_CHECK_ARG(ctx, planes || !(x_hi || x_lo || dy_hi || dy_lo), PP_ERR_ARG, "pp_conv2d_nhwc_bwd_weight_bf16x3: all four planes or none");
   PP_CHECK_ARG(ctx, !planes || (d->ld_x % 8 == 0 && d->ld_y % 8 == 0), PP_ERR_SHAPE, "pp_conv2d_nhwc_bwd_weight_bf16x3: planes need ld % 8 == 0");
+  PP_CHECK_ARG(ctx, !planes || (pp_is_packed(x_hi, x_lo) && pp_is_packed(dy_hi, dy_lo)), PP_ERR_ALIGN,
+               "pp_conv2d_nhwc_bwd_weight_bf16x3: planes must be packed (lo = hi + 16 bytes, 16-byte aligned)");
   PP_CHECK_ARG(ctx, d->cin % 64 == 0, PP_ERR_SHAPE, "pp_conv2d_nhwc_bwd_weight_bf16x3: cin %d must be a multiple of 64", d->cin);
   PP_CHECK_ARG(ctx, d->ld_y % 4 == 0 && d->ld_x % 4 == 0, PP_ERR_SHAPE, "pp_conv2d_nhwc_bwd_weight_bf16x3: leading dims must be multiples of 4");
   PP_CHECK_ARG(ctx, (!x || pp_is_aligned16(x)) && (!dy || pp_is_aligned16(dy)), PP_ERR_ALIGN,
@@ -2154,10 +2352,10 @@ extern "C" int pp_conv2d_nhwc_bwd_weight_bf16x3(pp_ctx* ctx, const pp_conv_desc*
       big_n = e[2] == '2';
     }
   }
-  if (big_k && big_n) launch_wgrad3<2, 2>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias, planes ? nullptr : skip_list);
-  else if (big_k) launch_wgrad3<2, 1>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias, planes ? nullptr : skip_list);
-  else if (big_n) launch_wgrad3<1, 2>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias, planes ? nullptr : skip_list);
-  else launch_wgrad3<1, 1>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias, planes ? nullptr : skip_list);
+  if (big_k && big_n) launch_wgrad3<2, 2>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias, skip_list);
+  else if (big_k) launch_wgrad3<2, 1>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias, skip_list);
+  else if (big_n) launch_wgrad3<1, 2>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias, skip_list);
+  else launch_wgrad3<1, 1>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias, skip_list);
   PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_weight_bf16x3");
   return PP_OK;
 }

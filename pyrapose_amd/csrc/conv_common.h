@@ -40,6 +40,12 @@ struct IgemmParams {
   // stride-2 bwd-data by parity class: enumerated row (n, y', x') of the class grid seg[0].OH x OW is written to (and
   // reads addend / mask at) row (n*sc_H + 2y' + sc_cy) * sc_W + 2x' + sc_cx of the full tensor
   int sc_on, sc_H, sc_W, sc_cy, sc_cx;
+  // epilogue operands stored as bf16 (hi, lo) planes instead of f32 (pp_ctx_set_epilogue_planes): the addend / residual
+  // (value = hi + lo, geometry [rows][ld_add]) and the ReLU source (only its hi plane is read: hi > 0 <=> value > 0,
+  // geometry [rows][ld_mask]).  When set they replace `addend` / `mask_src`.
+  const void* add_hi;
+  const void* add_lo;
+  const void* mask_hi;
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8, each with a private L2).

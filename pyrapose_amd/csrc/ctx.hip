@@ -54,6 +54,17 @@ extern "C" int pp_ctx_set_split_capture(pp_ctx* ctx, void* hi, void* lo) {
   return PP_OK;
 }
 
+extern "C" int pp_ctx_set_epilogue_planes(pp_ctx* ctx, const void* add_hi, const void* add_lo, const void* mask_hi) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, (add_hi == nullptr) == (add_lo == nullptr), PP_ERR_ARG, "pp_ctx_set_epilogue_planes: add_hi and add_lo go together");
+  PP_CHECK_ARG(ctx, pp_is_packed(add_hi, add_lo) && pp_is_aligned16(mask_hi), PP_ERR_ALIGN,
+               "pp_ctx_set_epilogue_planes: planes must be packed (lo = hi + 16 bytes) and 16-byte aligned");
+  ctx->ep_add_hi = add_hi;
+  ctx->ep_add_lo = add_lo;
+  ctx->ep_mask_hi = mask_hi;
+  return PP_OK;
+}
+
 extern "C" int pp_ctx_set_row_block_skip(pp_ctx* ctx, const unsigned char* flags, const int* list) {
   PP_REQUIRE_CTX(ctx);
   ctx->skip_flags = flags;

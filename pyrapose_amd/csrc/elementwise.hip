@@ -169,6 +169,199 @@ extern "C" int pp_add_n(pp_ctx* ctx, size_t n, const float* a, const float* b, c
   return PP_OK;
 }
 
+// ---- the same pointwise ops on tensor views: float32 or bf16 (hi, lo) planes (see pp_tview) ----
+// Every activation / gradient that a bf16x3 conv produces as planes only stays in that format through the FPN's adds and
+// resampling: 4 bytes per element either way, and the convs downstream never convert in their loops.
+struct TV {
+  const float* f;
+  const void* hi;
+  const void* lo;
+};
+static inline TV tv_of(const pp_tview* v) {
+  TV t = {nullptr, nullptr, nullptr};
+  if (v) { t.f = v->f32; t.hi = v->hi; t.lo = v->lo; }
+  return t;
+}
+static inline bool tv_null(const TV& t) { return !t.f && !t.hi; }
+static inline bool tv_ok_in(const TV& t) { return (t.f != nullptr) != (t.hi != nullptr) && pp_is_packed(t.hi, t.lo) && pp_is_aligned16(t.f); }
+static inline bool tv_ok_out(const TV& t) { return (t.f || t.hi) && pp_is_packed(t.hi, t.lo) && pp_is_aligned16(t.f); }
+
+// eight consecutive elements (one 32-byte group of a packed-plane tensor, two float4 of a float32 tensor)
+struct F8 { float4 a, b; };
+__device__ __forceinline__ F8 tv_ld8(const TV& t, size_t i8) {
+  F8 v;
+  if (t.hi) {
+    const uint4 h = reinterpret_cast<const uint4*>(t.hi)[2 * i8], l = reinterpret_cast<const uint4*>(t.hi)[2 * i8 + 1];
+    v.a.x = __uint_as_float(h.x << 16) + __uint_as_float(l.x << 16);
+    v.a.y = __uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u);
+    v.a.z = __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16);
+    v.a.w = __uint_as_float(h.y & 0xffff0000u) + __uint_as_float(l.y & 0xffff0000u);
+    v.b.x = __uint_as_float(h.z << 16) + __uint_as_float(l.z << 16);
+    v.b.y = __uint_as_float(h.z & 0xffff0000u) + __uint_as_float(l.z & 0xffff0000u);
+    v.b.z = __uint_as_float(h.w << 16) + __uint_as_float(l.w << 16);
+    v.b.w = __uint_as_float(h.w & 0xffff0000u) + __uint_as_float(l.w & 0xffff0000u);
+    return v;
+  }
+  v.a = reinterpret_cast<const float4*>(t.f)[2 * i8];
+  v.b = reinterpret_cast<const float4*>(t.f)[2 * i8 + 1];
+  return v;
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v;
+  v[0] = (__bf16)a;
+  v[1] = (__bf16)b;
+  return *reinterpret_cast<unsigned*>(&v);
+}
+__device__ __forceinline__ void tv_st8(const TV& t, size_t i8, const F8& v) {
+  if (t.f) {
+    reinterpret_cast<float4*>(const_cast<float*>(t.f))[2 * i8] = v.a;
+    reinterpret_cast<float4*>(const_cast<float*>(t.f))[2 * i8 + 1] = v.b;
+  }
+  if (t.hi) {
+    const float e[8] = {v.a.x, v.a.y, v.a.z, v.a.w, v.b.x, v.b.y, v.b.z, v.b.w};
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = e[j] - (float)(__bf16)e[j];
+    uint4* dst = reinterpret_cast<uint4*>(const_cast<void*>(t.hi));
+    dst[2 * i8] = make_uint4(pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]), pack_bf16x2(e[4], e[5]), pack_bf16x2(e[6], e[7]));
+    dst[2 * i8 + 1] = make_uint4(pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3]), pack_bf16x2(r[4], r[5]), pack_bf16x2(r[6], r[7]));
+  }
+}
+__device__ __forceinline__ void f8_add(F8& v, const F8& w) {
+  v.a.x += w.a.x; v.a.y += w.a.y; v.a.z += w.a.z; v.a.w += w.a.w;
+  v.b.x += w.b.x; v.b.y += w.b.y; v.b.z += w.b.z; v.b.w += w.b.w;
+}
+
+__global__ void add_n_v_kernel(size_t n8, const TV a, const TV b, const TV c, const TV out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    F8 v = tv_ld8(a, i);
+    if (b.f || b.hi) f8_add(v, tv_ld8(b, i));
+    if (c.f || c.hi) f8_add(v, tv_ld8(c, i));
+    tv_st8(out, i, v);
+  }
+}
+
+__global__ void relu_v_kernel(size_t n8, const TV x, const TV y) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    F8 v = tv_ld8(x, i);
+    v.a.x = fmaxf(v.a.x, 0.f); v.a.y = fmaxf(v.a.y, 0.f); v.a.z = fmaxf(v.a.z, 0.f); v.a.w = fmaxf(v.a.w, 0.f);
+    v.b.x = fmaxf(v.b.x, 0.f); v.b.y = fmaxf(v.b.y, 0.f); v.b.z = fmaxf(v.b.z, 0.f); v.b.w = fmaxf(v.b.w, 0.f);
+    tv_st8(y, i, v);
+  }
+}
+
+__global__ void upsample_add_fwd_v_kernel(int n_img, int sh, int sw, int th, int tw, int c8, float scale_y, float scale_x, const TV src,
+                                          const TV other, const TV out) {
+  const size_t total = (size_t)n_img * th * tw * c8;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % c8);
+    size_t t = i / c8;
+    int x = (int)(t % tw);
+    t /= tw;
+    int y = (int)(t % th);
+    int n = (int)(t / th);
+    int sy = nn_src(y, scale_y, sh), sx = nn_src(x, scale_x, sw);
+    F8 v = tv_ld8(src, ((size_t)(n * sh + sy) * sw + sx) * c8 + c);
+    if (other.f || other.hi) f8_add(v, tv_ld8(other, i));
+    tv_st8(out, i, v);
+  }
+}
+
+__global__ void upsample_add_bwd_v_kernel(int n_img, int sh, int sw, int th, int tw, int c8, float scale_y, float scale_x, float inv_y,
+                                          float inv_x, const TV dtarget, const TV base, const TV dsrc) {
+  const size_t total = (size_t)n_img * sh * sw * c8;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % c8);
+    size_t t = i / c8;
+    int sx = (int)(t % sw);
+    t /= sw;
+    int sy = (int)(t % sh);
+    int n = (int)(t / sh);
+    F8 acc;
+    acc.a = acc.b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (base.f || base.hi) acc = tv_ld8(base, i);
+    int y_lo = (int)(sy * inv_y) - 2, y_hi = (int)((sy + 1) * inv_y) + 2;
+    int x_lo = (int)(sx * inv_x) - 2, x_hi = (int)((sx + 1) * inv_x) + 2;
+    y_lo = y_lo < 0 ? 0 : y_lo; x_lo = x_lo < 0 ? 0 : x_lo;
+    y_hi = y_hi > th - 1 ? th - 1 : y_hi; x_hi = x_hi > tw - 1 ? tw - 1 : x_hi;
+    for (int y = y_lo; y <= y_hi; ++y) {
+      if (nn_src(y, scale_y, sh) != sy) continue;
+      for (int x = x_lo; x <= x_hi; ++x) {
+        if (nn_src(x, scale_x, sw) != sx) continue;
+        f8_add(acc, tv_ld8(dtarget, ((size_t)(n * th + y) * tw + x) * c8 + c));
+      }
+    }
+    tv_st8(dsrc, i, acc);
+  }
+}
+
+__global__ void merge_planes_kernel(size_t n8, const TV src, float4* __restrict__ dst) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const F8 v = tv_ld8(src, i);
+    dst[2 * i] = v.a;
+    dst[2 * i + 1] = v.b;
+  }
+}
+
+extern "C" int pp_add_n_v(pp_ctx* ctx, size_t n, const pp_tview* a, const pp_tview* b, const pp_tview* c, const pp_tview* out) {
+  PP_REQUIRE_CTX(ctx);
+  const TV ta = tv_of(a), tb = tv_of(b), tc = tv_of(c), to = tv_of(out);
+  PP_CHECK_ARG(ctx, n % 8 == 0 && tv_ok_in(ta) && (tv_null(tb) || tv_ok_in(tb)) && (tv_null(tc) || tv_ok_in(tc)) && tv_ok_out(to), PP_ERR_ARG,
+               "pp_add_n_v: bad views (n %% 8 == 0; an input is f32 or packed planes, 16-byte aligned)");
+  if (n == 0) return PP_OK;
+  hipLaunchKernelGGL(add_n_v_kernel, dim3(grid_for(n / 8, 256, ctx)), dim3(256), 0, ctx->stream, n / 8, ta, tb, tc, to);
+  PP_CHECK_LAUNCH(ctx, "pp_add_n_v");
+  return PP_OK;
+}
+
+extern "C" int pp_relu_fwd_v(pp_ctx* ctx, size_t n, const pp_tview* x, const pp_tview* y) {
+  PP_REQUIRE_CTX(ctx);
+  const TV tx = tv_of(x), ty = tv_of(y);
+  PP_CHECK_ARG(ctx, n % 8 == 0 && tv_ok_in(tx) && tv_ok_out(ty), PP_ERR_ARG, "pp_relu_fwd_v: bad views");
+  if (n == 0) return PP_OK;
+  hipLaunchKernelGGL(relu_v_kernel, dim3(grid_for(n / 8, 256, ctx)), dim3(256), 0, ctx->stream, n / 8, tx, ty);
+  PP_CHECK_LAUNCH(ctx, "pp_relu_fwd_v");
+  return PP_OK;
+}
+
+extern "C" int pp_upsample_nearest_add_fwd_v(pp_ctx* ctx, int n_img, int sh, int sw, int th, int tw, int c, const pp_tview* src,
+                                             const pp_tview* other, const pp_tview* out) {
+  PP_REQUIRE_CTX(ctx);
+  const TV ts = tv_of(src), to = tv_of(other), tout = tv_of(out);
+  PP_CHECK_ARG(ctx, n_img > 0 && sh > 0 && sw > 0 && th > 0 && tw > 0 && c > 0 && c % 8 == 0, PP_ERR_SHAPE, "pp_upsample_nearest_add_fwd_v: bad shape (c %% 8 == 0)");
+  PP_CHECK_ARG(ctx, tv_ok_in(ts) && (tv_null(to) || tv_ok_in(to)) && tv_ok_out(tout), PP_ERR_ARG, "pp_upsample_nearest_add_fwd_v: bad views");
+  size_t total = (size_t)n_img * th * tw * (c / 8);
+  hipLaunchKernelGGL(upsample_add_fwd_v_kernel, dim3(grid_for(total, 256, ctx)), dim3(256), 0, ctx->stream, n_img, sh, sw, th, tw, c / 8,
+                     (float)sh / (float)th, (float)sw / (float)tw, ts, to, tout);
+  PP_CHECK_LAUNCH(ctx, "pp_upsample_nearest_add_fwd_v");
+  return PP_OK;
+}
+
+extern "C" int pp_upsample_nearest_add_bwd_v(pp_ctx* ctx, int n_img, int sh, int sw, int th, int tw, int c, const pp_tview* dtarget,
+                                             const pp_tview* base, const pp_tview* dsrc) {
+  PP_REQUIRE_CTX(ctx);
+  const TV td = tv_of(dtarget), tb = tv_of(base), ts = tv_of(dsrc);
+  PP_CHECK_ARG(ctx, n_img > 0 && sh > 0 && sw > 0 && th > 0 && tw > 0 && c > 0 && c % 8 == 0, PP_ERR_SHAPE, "pp_upsample_nearest_add_bwd_v: bad shape (c %% 8 == 0)");
+  PP_CHECK_ARG(ctx, tv_ok_in(td) && (tv_null(tb) || tv_ok_in(tb)) && tv_ok_out(ts), PP_ERR_ARG, "pp_upsample_nearest_add_bwd_v: bad views");
+  size_t total = (size_t)n_img * sh * sw * (c / 8);
+  hipLaunchKernelGGL(upsample_add_bwd_v_kernel, dim3(grid_for(total, 256, ctx)), dim3(256), 0, ctx->stream, n_img, sh, sw, th, tw, c / 8,
+                     (float)sh / (float)th, (float)sw / (float)tw, (float)th / (float)sh, (float)tw / (float)sw, td, tb, ts);
+  PP_CHECK_LAUNCH(ctx, "pp_upsample_nearest_add_bwd_v");
+  return PP_OK;
+}
+
+extern "C" int pp_merge_planes_bf16x3(pp_ctx* ctx, size_t n, const void* hi, const void* lo, float* dst) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, hi && lo && dst && n % 8 == 0 && pp_is_packed(hi, lo) && pp_is_aligned16(dst), PP_ERR_ARG,
+               "pp_merge_planes_bf16x3: null / unaligned tensor, planes not packed, or n %% 8 != 0");
+  if (n == 0) return PP_OK;
+  TV t = {nullptr, hi, lo};
+  hipLaunchKernelGGL(merge_planes_kernel, dim3(grid_for(n / 8, 256, ctx)), dim3(256), 0, ctx->stream, n / 8, t, (float4*)dst);
+  PP_CHECK_LAUNCH(ctx, "pp_merge_planes_bf16x3");
+  return PP_OK;
+}
+
 // ---- packed-RGB stem input ----------------------------------------------------------------------
 __global__ void pack_rgb4_kernel(size_t n_pix, const float* __restrict__ x3, float4* __restrict__ x4) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_pix; i += (size_t)gridDim.x * blockDim.x)

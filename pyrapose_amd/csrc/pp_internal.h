@@ -17,6 +17,9 @@ struct pp_ctx {
   size_t ws_bytes;
   void* cap_hi;     // one-shot: the next bf16x3 fwd / bwd-data launch also writes the split of its gathered operand here
   void* cap_lo;
+  const void* ep_add_hi;  // one-shot: the next bf16x3 fwd / bwd-data launch reads its addend (residual) and / or its ReLU source
+  const void* ep_add_lo;  // from bf16 (hi, lo) planes (pp_ctx_set_epilogue_planes)
+  const void* ep_mask_hi;
   const int* skip_list;              // one-shot: row-block skip of the next bf16x3 bwd-weight (list) / bwd-data (flags) call
   const unsigned char* skip_flags;
 };
@@ -69,3 +72,7 @@ static inline int pp_rowspace_ok(const pp_rowspace* rs) {
 }
 
 static inline int pp_is_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+// packed (hi, lo) planes: one buffer of 32-byte groups (8 channels: 16 bytes of hi, 16 bytes of lo); lo = hi + 16 bytes
+static inline int pp_is_packed(const void* hi, const void* lo) {
+  return (hi == nullptr && lo == nullptr) || (hi != nullptr && (const char*)lo == (const char*)hi + 16 && pp_is_aligned16(hi));
+}

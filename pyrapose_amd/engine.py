@@ -42,35 +42,68 @@ class Op(object):
 
 
 class Act(object):
-    """A level-major activation matrix [rows, ld] (see pp_rowspace)."""
+    """A level-major activation matrix [rows, ld] (see pp_rowspace), stored as float32 (`t`) or -- what the bf16x3 convs
+    produce and consume in the default mode -- as a pair of bf16 planes (`pl` = (hi, lo) int16 [rows, ld], value = hi + lo)."""
 
-    def __init__(self, name, n_img, shapes, C, ld=None, t=None, needs_grad=False, relu=False):
+    def __init__(self, name, n_img, shapes, C, ld=None, t=None, needs_grad=False, relu=False, pl=None, planes=False):
         self.name, self.n_img, self.shapes, self.C = name, n_img, list(shapes), C
         self.ld = ld if ld is not None else C
         self.rows = sum(n_img * h * w for h, w in self.shapes)
-        self.t = t if t is not None else torch.empty((self.rows, self.ld), dtype=torch.float32, device="cuda")
+        if planes:
+            self.t = None
+            self.pl = pl if pl is not None else _new_planes(self.rows, self.ld)
+        else:
+            self.t = t if t is not None else torch.empty((self.rows, self.ld), dtype=torch.float32, device="cuda")
+            self.pl = None
         self.needs_grad, self.relu = needs_grad, relu
         self.contribs = []
         self.prod_ops = []  # forward launches that write this tensor (an alias lists those of its parts)
-        self.pl = None  # (hi, lo) int16 [rows, ld]: the same matrix pre-split into bf16 planes (bf16x3 mode, conv-produced)
 
     def rowspace(self):
         return RowSpace.make(self.n_img, self.shapes)
 
+    def view(self):
+        return _view(self.t, self.pl)
+
+    def f32(self, ctx):
+        """the matrix as float32 (a copy merged from the planes when that is how it is stored): tests / inspection"""
+        if self.t is not None:
+            return self.t
+        out = torch.empty((self.rows, self.ld), dtype=torch.float32, device="cuda")
+        ops.merge_planes3(ctx, self.pl, out)
+        return out
+
 
 def _new_planes(rows, ld):
-    return tuple(torch.zeros((rows, ld), dtype=torch.int16, device="cuda") for _ in range(2))
+    return ops.new_planes(rows, ld)
+
+
+def _view(t, pl):
+    """input view of a tensor that exists as float32 and / or planes (the float32 copy wins: it is the exact one)"""
+    return ops.tview(t, None) if t is not None else ops.tview(None, pl)
 
 
 class Grad(object):
-    """A gradient matrix and, when a bf16x3 kernel (or an explicit split) produced it, its bf16 planes."""
+    """A gradient matrix: float32 (`t`) and / or bf16 planes (`pl`); rows(a, b) = the same for a row range."""
     __slots__ = ("t", "pl")
 
     def __init__(self, t, pl=None):
         self.t, self.pl = t, pl
 
     def rows(self, r0, r1):
-        return Grad(self.t[r0:r1], None if self.pl is None else (self.pl[0][r0:r1], self.pl[1][r0:r1]))
+        return Grad(None if self.t is None else self.t[r0:r1], None if self.pl is None else (self.pl[0][r0:r1], self.pl[1][r0:r1]))
+
+    def view(self):
+        return _view(self.t, self.pl)
+
+    def shape(self):
+        if self.t is not None:
+            return tuple(self.t.shape)
+        return (self.pl[0].shape[0], ops.planes_ld(self.pl))  # packed planes: views [rows, ld / 8, 8] of one buffer
+
+    def contiguous(self):
+        """whole rows, one after the other (a row range of a matrix qualifies; packed planes always do)"""
+        return self.t.is_contiguous() if self.t is not None else True
 
 
 class ParamStore(object):
@@ -215,23 +248,28 @@ class Engine(object):
         # "f32" = exact f32 MFMA everywhere (conv.hip).  Both hold the 1e-3 head-output bar.
         self.conv_mode = conv_mode or _os.environ.get("PP_CONV_MODE", "bf16x3")
         assert self.conv_mode in ("f32", "bf16x3"), self.conv_mode
-        # PP_ACT_PLANES=1: conv epilogues also write their output pre-split into bf16 planes and the weight-gradient
-        # launches read both operands from planes (gradients that only convs read are then never stored in f32).
-        # Measured on the bench workload: bwd-weight -0.8 ms, forward + bwd-data epilogues +0.6..1.0 ms -> off by default.
-        self.use_act_planes = self.conv_mode == "bf16x3" and _os.environ.get("PP_ACT_PLANES", "0") == "1"
+        # Storage format of activations and gradients in bf16x3 mode (PP_PLANES=0 turns it off): every tensor that a bf16x3 conv
+        # produces is written as bf16 (hi, lo) planes ONLY -- 4 bytes per element like float32 -- and stays in that format
+        # through the FPN's adds / resampling; convs read their gathered operand, the weight gradients both operands, and the
+        # epilogues their residual / addend / ReLU source from planes, so no kernel converts f32 -> bf16 inside its loop.
+        # The products are the same as with the in-loop split (same hi, lo); a value read back from planes (residuals, adds)
+        # is within 2^-17 of the float32 it was split from.  float32 stays for: the image, conv1 / pool1 (frozen prefix), the
+        # three head outputs (losses, export) and the loss gradients.
+        self.po = self.conv_mode == "bf16x3" and _os.environ.get("PP_PLANES", "1") != "0"
+        self.use_act_planes = False  # (the round-1 "both formats" mode is gone: planes-only supersedes it)
         # split capture (PP_CAPTURE=1): the forward / bwd-data launch of a 3x3 stride-1 conv also stores the bf16 split of
         # its gathered operand (it has just computed it), and the weight-gradient launch of the layer, enqueued after the
         # layer's bwd-data launch, reads both operands pre-split.  Off by default: the weight-gradient kernel alone gains
         # 11-15 % and the capture costs the 512-channel launches nothing, but the training step does not move (one lane:
         # +0.6 %; two lanes: -1 % -- with both lanes busy the MFMA pipes, not the conversion VALU, are what is shared).
-        self.capture = (self.conv_mode == "bf16x3" and not self.use_act_planes and _os.environ.get("PP_CAPTURE", "0") == "1")
+        self.capture = (self.conv_mode == "bf16x3" and not self.po and _os.environ.get("PP_CAPTURE", "0") == "1")
         # Sparse backward of the 3D-box head (PP_SPARSE_BWD=0 disables): orthogonal_l1 keeps the rows with anchor state 1 only
         # (losses.py:332-333), so the gradient entering that head -- and, dilated by one pixel per 3x3 layer, every gradient
         # inside it -- is exactly zero away from the positive anchors.  One scan per layer lists the 32-row blocks that hold a
         # non-zero (pp_row_block_list); the weight gradient reduces over those blocks only and the data gradient skips the
         # output tiles that cannot see one.  Exact: a zero row adds 0.0 to every sum.
         self.sparse_bwd = tuple(t for t in _os.environ.get("PP_SPARSE_BWD", "reg").split(",") if t and t != "0") \
-            if self.conv_mode == "bf16x3" and not self.use_act_planes else ()
+            if self.conv_mode == "bf16x3" else ()
         self.capture_min_cin = int(_os.environ.get("PP_CAPTURE_MIN_CIN", "64"))
         self.capture_skip = tuple(t for t in _os.environ.get("PP_CAPTURE_SKIP", "").split(",") if t)
         self.planes = OrderedDict()  # spec name -> dict(desc, fwd_hi, fwd_lo, dg_hi, dg_lo)
@@ -301,8 +339,8 @@ class Engine(object):
             cur.wait_stream(self.streams[0])
 
     # ------------------------------------------------------------------------------------ forward plan
-    def _new_act(self, name, shapes, C, ld=None, needs_grad=False, relu=False, t=None):
-        a = Act(name, self.B, shapes, C, ld, t, needs_grad, relu)
+    def _new_act(self, name, shapes, C, ld=None, needs_grad=False, relu=False, t=None, pl=None, planes=False):
+        a = Act(name, self.B, shapes, C, ld, t, needs_grad, relu, pl, planes)
         self.acts[name] = a
         return a
 
@@ -344,7 +382,8 @@ class Engine(object):
                             waits.append(p.done_ev)
             op.waits = tuple(waits)
 
-    def _conv(self, spec_name, x, out_name=None, relu=False, residual=None, out_t=None, out_ld=None, out_pl=None):
+    def _conv(self, spec_name, x, out_name=None, relu=False, residual=None, out_t=None, out_ld=None, out_pl=None, f32_out=False):
+        """f32_out: keep the output in float32 even in planes mode (the head outputs: read by the losses and the export)"""
         s = self.params.specs[spec_name]
         k, st = s.k, s.stride
         cin_eff = 4 if s.cin == 3 else s.cin
@@ -362,18 +401,19 @@ class Engine(object):
         # head outputs are padded to 32 channels in bf16x3 mode (the bf16 data-gradient kernel reduces 32 channels per step)
         ld_y = out_ld if out_ld is not None else _ru(s.cout, 32 if self.conv_mode == "bf16x3" else 16)
         needs_grad = self.train and (s.trainable or x.needs_grad or (residual is not None and residual.needs_grad))
-        y = self._new_act(out_name or spec_name, out_shapes, s.cout, ld_y, needs_grad, relu, out_t)
+        bf3 = self.conv_mode == "bf16x3" and s.cin % 32 == 0
+        y_planes = bf3 and self.po and not f32_out and ld_y % 8 == 0
+        y = self._new_act(out_name or spec_name, out_shapes, s.cout, ld_y, needs_grad, relu, out_t, out_pl, y_planes)
         ek = self.params.entries[spec_name + "/kernel"]
         desc = ops.make_conv_desc(self.B, x.shapes, out_shapes, cin_eff, s.cout, k, st, pt, pl, x.ld, ld_y, ek["ld"])
         w = self.params.view(self.params.w_eff, spec_name + "/kernel")
         b = self.params.view(self.params.w_eff, spec_name + "/bias")
         lane = self._lane
         ctx = self.ctxs[lane]
-        rt = residual.t if residual is not None else None
         flops = 2.0 * y.rows * k * k * s.cin * s.cout
         pl = None
         x_cap = None
-        if self.conv_mode == "bf16x3" and s.cin % 32 == 0:
+        if bf3:
             pl = self.planes.get(spec_name)
             if pl is None:
                 i16 = dict(dtype=torch.int16, device="cuda")
@@ -384,22 +424,22 @@ class Engine(object):
                           dg_lo=torch.zeros((k * k, s.cin, _ru(s.cout, 32)), **i16) if need_dg else None)
                 self.planes[spec_name] = pl
             fh, fl = pl["fwd_hi"], pl["fwd_lo"]
-            if self.use_act_planes:
-                y.pl = out_pl if out_pl is not None else _new_planes(y.rows, y.ld)
-            # pre-split operands pay in the weight-gradient kernel (+25 %: its f32 path converts both operands in the
-            # loop); forward / bwd-data run equally fast from f32 (the conversion hides under their MFMAs), so planes
-            # are written only for tensors that a weight-gradient launch will read
-            if self._wants_planes(s):
-                x.conv3_consumers = getattr(x, "conv3_consumers", 0) + 1
             y.producer = s
             cap = None
             if self._wants_capture(s, x):
                 if getattr(x, "cap_pl", None) is None:  # the first eligible consumer of x fills the planes
                     x.cap_pl = cap = _new_planes(x.rows, x.ld)
                 x_cap = x.cap_pl
-            self._push(Op(lambda: ops.conv_fwd3(ctx, desc, x.t, fh, fl, b, rt, relu, y.t, x.pl, y.pl, cap), "conv_fwd", spec_name,
+            # operands in the format they exist in: planes where a tensor has no float32 copy
+            x_t, x_pl = (x.t, None) if x.t is not None else (None, x.pl)
+            r_t = r_pl = None
+            if residual is not None:
+                r_t, r_pl = (residual.t, None) if residual.t is not None else (None, residual.pl)
+            self._push(Op(lambda: ops.conv_fwd3(ctx, desc, x_t, fh, fl, b, r_t, relu, y.t, x_pl, y.pl, cap, r_pl), "conv_fwd", spec_name,
                           flops, None, lane), (x, residual), y)
         else:
+            assert x.t is not None and (residual is None or residual.t is not None), spec_name
+            rt = residual.t if residual is not None else None
             self._push(Op(lambda: ops.conv_fwd(ctx, desc, x.t, w, b, rt, relu, y.t), "conv_fwd", spec_name, flops, None, lane),
                        (x, residual), y)
         self.graph_ops.append(dict(kind="conv", spec=s, x=x, y=y, residual=residual, desc=desc, w=w, flops=flops, planes=pl,
@@ -408,15 +448,11 @@ class Engine(object):
 
     def _wants_capture(self, s, x):
         return (self.train and self.capture and s.trainable and x.needs_grad and s.k == 3 and s.stride == 1 and (s.pad == "same" or str(s.pad) == "1")
-                and s.cin % 64 == 0 and s.cout % 32 == 0 and s.cin >= self.capture_min_cin and x.ld % 8 == 0 and x.pl is None
+                and s.cin % 64 == 0 and s.cout % 32 == 0 and s.cin >= self.capture_min_cin and x.ld % 8 == 0 and x.t is not None
                 and not any(s.name.startswith(t) for t in self.capture_skip) and not self._sparse_layer(s))
 
     def _sparse_layer(self, s):
         return self.train and s.k == 3 and s.stride == 1 and s.cin % 64 == 0 and any(s.name.startswith(t) for t in self.sparse_bwd)
-
-    def _wants_planes(self, s):
-        # worth it only where the weight-gradient launch is big and conversion-bound: the wide 3x3 convs (regression head)
-        return self.train and s.trainable and s.cin % 64 == 0 and s.k == 3 and s.cin >= int(_os.environ.get("PP_PLANES_MIN_CIN", "512"))
 
     def _build_forward(self):
         B, H, W = self.B, self.H, self.W
@@ -471,7 +507,7 @@ class Engine(object):
             y = feat
             for i in range(4):
                 y = self._conv("%s_conv%d" % (prefix, i), y, relu=True)
-            return self._conv(prefix + "_out", y)
+            return self._conv(prefix + "_out", y, f32_out=True)
         self.fwd_fork = len(self.fwd_ops)  # everything before this index is the serial trunk (lane 0)
         self._lane = 0
         self.reg_out = run_head("reg", pyr)
@@ -490,10 +526,6 @@ class Engine(object):
                     mixed.append(c[i])
         self.fwd_ops = trunk + mixed
         self._link_lanes()
-        # planes nobody reads are not written (the forward closures read .pl at call time)
-        for a in self.acts.values():
-            if a.pl is not None and not getattr(a, "conv3_consumers", 0) and a.pl[0]._base is None:  # (P4/P5 write slices of pyr's)
-                a.pl = None
 
     def _build_stem3(self, x4):
         B, H, W = self.B, self.H, self.W
@@ -528,13 +560,13 @@ class Engine(object):
         """P3 | P4 | ... rows in one buffer, so that the shared heads run as ONE multi-level launch"""
         B = self.B
         rows = [B * h * w for h, w in level_shapes]
-        pyr_t = torch.empty((sum(rows), 256), dtype=torch.float32, device="cuda")
+        pyr_t = None if self.po else torch.empty((sum(rows), 256), dtype=torch.float32, device="cuda")
         cuts, r0 = [], 0
         for n in rows:
             cuts.append((r0, r0 + n))
             r0 += n
-        sl = [pyr_t[a:b] for a, b in cuts]
-        pyr_pl = _new_planes(sum(rows), 256) if self.use_act_planes else None
+        sl = [pyr_t[a:b] if pyr_t is not None else None for a, b in cuts]
+        pyr_pl = _new_planes(sum(rows), 256) if self.po else None
         spl = [(pyr_pl[0][a:b], pyr_pl[1][a:b]) if pyr_pl else None for a, b in cuts]
         return pyr_t, pyr_pl, rows, sl, spl
 
@@ -561,8 +593,7 @@ class Engine(object):
             F5 = self._add("fpn_fin5", [D4, L5])
             P5 = self._conv("P5", F5, out_t=sl[2], out_pl=spl[2])
         needs = self.train
-        pyr = self._new_act("pyramid", lv, 256, 256, needs, False, pyr_t)
-        pyr.pl = pyr_pl
+        pyr = self._new_act("pyramid", lv, 256, 256, needs, False, pyr_t, pyr_pl, pyr_pl is not None)
         pyr.producer = getattr(P3, "producer", None)
         pyr.prod_ops = [o for part in (P3, P4, P5) for o in part.prod_ops]
         self.graph_ops.append(dict(kind="alias", y=pyr, parts=[P3, P4, P5], rows=rows))
@@ -589,109 +620,106 @@ class Engine(object):
             R6 = self._relu("P6_relu", P6)                                      # :154
             P7 = self._conv("P7_con", R6, out_t=sl[4], out_pl=spl[4])           # :155
             parts += [P6, P7]
-        pyr = self._new_act("pyramid", lv, 256, 256, self.train, False, pyr_t)
-        pyr.pl = pyr_pl
+        pyr = self._new_act("pyramid", lv, 256, 256, self.train, False, pyr_t, pyr_pl, pyr_pl is not None)
         pyr.producer = getattr(P3, "producer", None)
         pyr.prod_ops = [o for part in parts for o in part.prod_ops]
         self.graph_ops.append(dict(kind="alias", y=pyr, parts=parts, rows=rows))
         return pyr, P3
 
     def _relu(self, name, x):
-        out = self._new_act(name, x.shapes, x.C, x.ld, x.needs_grad, True)
+        out = self._new_act(name, x.shapes, x.C, x.ld, x.needs_grad, True, planes=self.po)
         lane = self._lane
         ctx = self.ctxs[lane]
-        self._push(Op(lambda: ops.relu_fwd(ctx, x.t, out.t), "pointwise", name, lane=lane), (x,), out)
+        vx, vo = x.view(), out.view()
+        self._push(Op(lambda: ops.relu_fwd_v(ctx, vx, vo), "pointwise", name, lane=lane), (x,), out)
         self.graph_ops.append(dict(kind="relu", y=out, x=x))
         return out
 
     def _upadd(self, name, src, other):
         (sh, sw), (th, tw) = src.shapes[0], other.shapes[0]
-        out = self._new_act(name, [(th, tw)], src.C, src.ld, src.needs_grad or other.needs_grad)
+        out = self._new_act(name, [(th, tw)], src.C, src.ld, src.needs_grad or other.needs_grad, planes=self.po)
         lane, B = self._lane, self.B
         ctx = self.ctxs[lane]
-        self._push(Op(lambda: ops.upsample_add_fwd(ctx, B, sh, sw, th, tw, src.C, src.t, other.t, out.t), "pointwise", name, lane=lane),
+        vs, vt, vo = src.view(), other.view(), out.view()
+        self._push(Op(lambda: ops.upsample_add_fwd_v(ctx, B, sh, sw, th, tw, src.C, vs, vt, vo), "pointwise", name, lane=lane),
                    (src, other), out)
         self.graph_ops.append(dict(kind="upadd", y=out, src=src, other=other))
-        self._split_act(out)
         return out
 
-    def _split_act(self, act):
-        """FPN sums feed trainable 3x3 convs: give them planes with an explicit split launch (their producer is not a conv)."""
-        if self.train and self.use_act_planes and act.ld % 8 == 0:
-            act.pl = _new_planes(act.rows, act.ld)
-            lane = self._lane
-            ctx = self.ctxs[lane]
-            self._push(Op(lambda: ops.split_planes3(ctx, act.t, act.pl[0], act.pl[1]) if act.pl is not None else None,
-                          "pointwise", "split:" + act.name, lane=lane), (act,), act)
-
     def _add(self, name, ins):
-        out = self._new_act(name, ins[0].shapes, ins[0].C, ins[0].ld, any(i.needs_grad for i in ins))
+        out = self._new_act(name, ins[0].shapes, ins[0].C, ins[0].ld, any(i.needs_grad for i in ins), planes=self.po)
         lane = self._lane
         ctx = self.ctxs[lane]
-        a, b, c = ins[0].t, ins[1].t, (ins[2].t if len(ins) > 2 else None)
-        self._push(Op(lambda: ops.add_n(ctx, a, b, c, out.t), "pointwise", name, lane=lane), ins, out)
+        va, vb, vc = ins[0].view(), ins[1].view(), (ins[2].view() if len(ins) > 2 else None)
+        vo = out.view()
+        self._push(Op(lambda: ops.add_n_v(ctx, va, vb, vc, vo), "pointwise", name, lane=lane), ins, out)
         self.graph_ops.append(dict(kind="add", y=out, ins=ins))
-        self._split_act(out)
         return out
 
     # ------------------------------------------------------------------------------------ backward plan
-    def _finalize(self, act, planes_only=False):
+    def _new_grad(self, rows, ld):
+        """an uninitialised gradient matrix in the mode's storage format"""
+        if self.po and ld % 8 == 0:
+            return Grad(None, _new_planes(rows, ld))
+        return Grad(torch.empty((rows, ld), dtype=torch.float32, device="cuda"))
+
+    def _finalize(self, act):
         """Sum the gradient contributions of `act`; the ReLU mask (act > 0) is folded into the last
-        data-gradient launch.  Returns the gradient w.r.t. the pre-activation, or None.
-        planes_only: every reader of the result takes bf16 planes -> the f32 copy is not written at all."""
+        data-gradient launch.  Returns the gradient w.r.t. the pre-activation (a Grad), or None."""
         ctx = self.ctx
         grads = [c[1] for c in act.contribs if c[0] == "tensor"]
-        tensors = [g.t for g in grads]
         dgrads = [c for c in act.contribs if c[0] == "dgrad"]
-        if not tensors and not dgrads:
+        if not grads and not dgrads:
             return None
-        new = lambda: torch.empty((act.rows, act.ld), dtype=torch.float32, device="cuda")
         acc = None
-        if len(tensors) == 1:
-            acc = tensors[0]
-        elif len(tensors) > 1:
-            acc = new()
-            srcs, rest = tensors[:3], tensors[3:]
+        if len(grads) == 1:
+            acc = grads[0]
+        elif len(grads) > 1:
+            acc = self._new_grad(act.rows, act.ld)
+            srcs, rest = grads[:3], grads[3:]
             while True:
-                a, b, c = srcs[0], (srcs[1] if len(srcs) > 1 else None), (srcs[2] if len(srcs) > 2 else None)
-                self.bwd_ops.append(Op(lambda a=a, b=b, c=c, out=acc: ops.add_n(ctx, a, b, c, out), "pointwise", "add:" + act.name))
+                va, vb, vc = srcs[0].view(), (srcs[1].view() if len(srcs) > 1 else None), (srcs[2].view() if len(srcs) > 2 else None)
+                vo = ops.tview(acc.t, acc.pl)
+                self.bwd_ops.append(Op(lambda va=va, vb=vb, vc=vc, vo=vo: ops.add_n_v(ctx, va, vb, vc, vo), "pointwise", "add:" + act.name))
                 if not rest:
                     break
                 srcs, rest = [acc] + rest[:2], rest[2:]  # in-place accumulate (pointwise: safe)
         if act.relu and not dgrads:
             raise NotImplementedError("relu output %s without a data-gradient consumer" % act.name)
         if not dgrads:
-            g = grads[0] if len(tensors) == 1 else Grad(acc)
-            prod = getattr(act, "producer", None)
-            if g.pl is None and self.use_act_planes and prod is not None and self._wants_planes(prod) and act.ld % 8 == 0:
-                g = Grad(g.t, _new_planes(act.rows, act.ld))
-                self.bwd_ops.append(Op(lambda gt=g.t, pl=g.pl: ops.split_planes3(ctx, gt, pl[0], pl[1]), "pointwise", "split:g:" + act.name))
-            return g
-        opl = None
+            return acc
         for i, (_, op, gy) in enumerate(dgrads):
             last = i == len(dgrads) - 1
-            mask = act.t if (act.relu and last) else None
+            mask = act if (act.relu and last) else None
             pl = op.get("planes")
             if pl is not None and pl["dg_hi"] is not None:
-                prod = getattr(act, "producer", None)
-                # the finished gradient feeds the producer's dgrad/wgrad: hand it over pre-split
-                if last and self.use_act_planes and prod is not None and self._wants_planes(prod):
-                    opl = _new_planes(act.rows, act.ld)
-                out = None if (opl is not None and planes_only) else new()
+                out = self._new_grad(act.rows, act.ld)
                 gcap = op.get("g_cap")
-                sk = op.get("skip") if gy.pl is None else None
-                self.bwd_ops.append(Op(lambda d=op["desc"], gy=gy, dh=pl["dg_hi"], dl=pl["dg_lo"], acc=acc, mask=mask, out=out, opl=opl, gcap=gcap, sk=sk:
-                                       ops.conv_bwd_data3(ctx, d, gy.t, dh, dl, acc, mask, out, gy.pl, opl, gcap, sk), "conv_dgrad",
+                sk = op.get("skip")
+                # every operand in the format it exists in (planes where there is no float32 copy)
+                dy_t, dy_pl = (None, gy.pl) if gy.pl is not None else (gy.t, None)
+                a_t = a_pl = m_t = m_hi = None
+                if acc is not None:
+                    a_t, a_pl = (acc.t, None) if acc.t is not None else (None, acc.pl)
+                if mask is not None:
+                    m_t, m_hi = (mask.t, None) if mask.t is not None else (None, mask.pl[0])
+                if gcap is not None:
+                    assert dy_t is not None
+                self.bwd_ops.append(Op(lambda d=op["desc"], dy_t=dy_t, dy_pl=dy_pl, dh=pl["dg_hi"], dl=pl["dg_lo"], a_t=a_t, a_pl=a_pl, m_t=m_t,
+                                       m_hi=m_hi, out=out, gcap=gcap, sk=sk:
+                                       ops.conv_bwd_data3(ctx, d, dy_t, dh, dl, a_t, m_t, out.t, dy_pl, out.pl, gcap, sk, a_pl, m_hi), "conv_dgrad",
                                        op["spec"].name, op["flops"]))
                 pw = op.pop("pending_wgrad", None)
                 if pw is not None:  # the layer's weight gradient reads the planes this launch has just written
                     self.bwd_ops.append(pw)
             else:
-                out = new()
-                self.bwd_ops.append(Op(lambda d=op["desc"], gy=gy, w=op["w"], acc=acc, mask=mask, out=out:
-                                       ops.conv_bwd_data(ctx, d, gy.t, w, acc, mask, out), "conv_dgrad", op["spec"].name, op["flops"]))
+                assert gy.t is not None and (acc is None or acc.t is not None) and (mask is None or mask.t is not None), act.name
+                out = Grad(torch.empty((act.rows, act.ld), dtype=torch.float32, device="cuda"))
+                self.bwd_ops.append(Op(lambda d=op["desc"], gy=gy, w=op["w"], a=(acc.t if acc is not None else None),
+                                       m=(mask.t if mask is not None else None), out=out:
+                                       ops.conv_bwd_data(ctx, d, gy.t, w, a, m, out.t), "conv_dgrad", op["spec"].name, op["flops"]))
             acc = out
-        return Grad(acc, opl)
+        return acc
 
     def _build_backward(self):
         ctx, P = self.ctx, self.params
@@ -701,7 +729,8 @@ class Engine(object):
         self.g_mask = torch.zeros((self.mask_out.rows, self.mask_out.ld), **f32)
         for out, gt in ((self.reg_out, self.g_reg), (self.cls_out, self.g_cls), (self.mask_out, self.g_mask)):
             g = Grad(gt)
-            if self.use_act_planes:
+            if self.po and out.ld % 8 == 0:
+                # the loss kernels write float32; the head's last conv takes its dy (bwd-data, bwd-weight) from planes
                 g.pl = _new_planes(out.rows, out.ld)
                 self.bwd_ops.append(Op(lambda gt=gt, pl=g.pl: ops.split_planes3(ctx, gt, pl[0], pl[1]), "pointwise", "split:" + out.name))
             out.contribs.append(("tensor", g))
@@ -712,27 +741,22 @@ class Engine(object):
             y = op["y"]
             if not y.needs_grad:
                 continue
-            po = False
-            if kind == "conv" and self.use_act_planes:
-                # the gradient of a conv output is read by that conv's bwd-data and bwd-weight launches only (plus its
-                # residual input, in f32): when both take planes, the f32 copy of the gradient is never materialised
-                s_, x_, r_ = op["spec"], op["x"], op["residual"]
-                pl_ = op.get("planes")
-                dgrad3_ok = (not x_.needs_grad) or (pl_ is not None and pl_["dg_hi"] is not None)
-                wgrad3_ok = (not s_.trainable) or (s_.cin % 64 == 0 and x_.pl is not None)
-                po = dgrad3_ok and wgrad3_ok and not (r_ is not None and r_.needs_grad) and self._wants_planes(s_)
-            g = self._finalize(y, po)
+            g = self._finalize(y)
             if g is None:
                 continue
             if kind == "conv":
                 s, x = op["spec"], op["x"]
-                if self._sparse_layer(s) and g.pl is None and g.t.is_contiguous() and g.t.dim() == 2:
-                    nb = (g.t.shape[0] + 31) // 32
+                if self._sparse_layer(s) and g.contiguous() and len(g.shape()) == 2:
+                    nb = (g.shape()[0] + 31) // 32
                     skip = op["skip"] = (torch.zeros((2 * nb,), dtype=torch.uint8, device="cuda"),   # flags | bwd-data scratch
                                          torch.zeros((2 * (nb + 1),), dtype=torch.int32, device="cuda"))
-                    cols = min((y.C + 3) // 4 * 4, g.t.shape[1])
-                    self.bwd_ops.append(Op(lambda gt=g.t, cols=cols, skip=skip: ops.row_block_list(ctx, gt, cols, skip[0], skip[1]),
-                                           "pointwise", "rowblocks:" + s.name))
+                    cols = min((y.C + 3) // 4 * 4, g.shape()[1])
+                    if g.t is not None:
+                        self.bwd_ops.append(Op(lambda gt=g.t, cols=cols, skip=skip: ops.row_block_list(ctx, gt, cols, skip[0], skip[1]),
+                                               "pointwise", "rowblocks:" + s.name))
+                    else:
+                        self.bwd_ops.append(Op(lambda gp=g.pl, cols=cols, skip=skip: ops.row_block_list_planes(ctx, gp, cols, skip[0], skip[1]),
+                                               "pointwise", "rowblocks:" + s.name))
                 if s.trainable:
                     dw = P.view(P.grad, s.name + "/kernel")
                     db = P.view(P.grad, s.name + "/bias") if s.bias else None
@@ -750,11 +774,15 @@ class Engine(object):
                         op["pending_wgrad"] = Op(fn, "conv_wgrad", s.name, op["flops"], wr, wl)  # enqueued after the layer's dgrad
                         fn = None
                     elif self.conv_mode == "bf16x3" and s.cin % 64 == 0:
+                        # both operands as planes where both exist as planes (no conversion in the loop), else both as float32
                         both = x.pl is not None and g.pl is not None
-                        sk = None if both else op.get("skip")
-                        fn = lambda d=op["desc"], x=x, g=g, dw=dw, db=db, wctx=wctx, xp=(x.pl if both else None), gp=(g.pl if both else None), sk=sk: \
-                            ops.conv_bwd_weight3(wctx, d, x.t, g.t, dw, db, xp, gp, sk)
+                        assert both or (x.t is not None and g.t is not None), "weight gradient of %s: operands in different formats" % s.name
+                        sk = op.get("skip")
+                        fn = lambda d=op["desc"], xt=(None if both else x.t), gt=(None if both else g.t), dw=dw, db=db, wctx=wctx, \
+                            xp=(x.pl if both else None), gp=(g.pl if both else None), sk=sk: \
+                            ops.conv_bwd_weight3(wctx, d, xt, gt, dw, db, xp, gp, sk)
                     else:
+                        assert x.t is not None and g.t is not None, s.name
                         fn = lambda d=op["desc"], xt=x.t, g=g, dw=dw, db=db, wctx=wctx: ops.conv_bwd_weight(wctx, d, xt, g.t, dw, db)
                     if fn is not None:
                         self.bwd_ops.append(Op(fn, "conv_wgrad", s.name, op["flops"], wr, wl))
@@ -772,11 +800,12 @@ class Engine(object):
                 if other.needs_grad:
                     other.contribs.append(("tensor", g))
                 if src.needs_grad:
-                    gs = torch.empty((src.rows, src.ld), **f32)
+                    gs = self._new_grad(src.rows, src.ld)
                     (sh, sw), (th, tw) = src.shapes[0], other.shapes[0]
-                    self.bwd_ops.append(Op(lambda g=g, gs=gs, sh=sh, sw=sw, th=th, tw=tw, c=src.C:
-                                           ops.upsample_add_bwd(ctx, self.B, sh, sw, th, tw, c, g.t, None, gs), "pointwise", "upbwd:" + src.name))
-                    src.contribs.append(("tensor", Grad(gs)))
+                    vg, vs = g.view(), ops.tview(gs.t, gs.pl)
+                    self.bwd_ops.append(Op(lambda vg=vg, vs=vs, sh=sh, sw=sw, th=th, tw=tw, c=src.C:
+                                           ops.upsample_add_bwd_v(ctx, self.B, sh, sw, th, tw, c, vg, None, vs), "pointwise", "upbwd:" + src.name))
+                    src.contribs.append(("tensor", gs))
             elif kind == "relu":
                 # `g` already carries the mask (y > 0): _finalize folded it into the data-gradient launch that produced it
                 if op["x"].needs_grad:

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from ._lib import ConvDesc, ParamDesc, RowSpace, check, lib
+from ._lib import ConvDesc, ParamDesc, RowSpace, TView, check, lib
 
 
 def _ptr(t):
@@ -112,6 +112,27 @@ class SplitWeightsBatch(object):
               "pp_conv_split_weights_bf16x3_batch")
 
 
+def new_planes(rows, ld, device="cuda", fill=0):
+    """A tensor [rows][ld] (ld % 8 == 0) as PACKED bf16 planes: one buffer of rows * ld * 4 bytes cut into 32-byte groups of 8
+    channels -- 16 bytes of hi, 16 bytes of lo (value = hi + lo).  Returns the (hi, lo) pair the C ABI takes: int16 views
+    [rows, ld / 8, 8] of that buffer with lo.data_ptr() == hi.data_ptr() + 16; row slices of both stay valid pairs."""
+    assert ld % 8 == 0, ld
+    base = torch.full((rows, ld // 8, 2, 8), fill, dtype=torch.int16, device=device)
+    return base[:, :, 0, :], base[:, :, 1, :]
+
+
+def planes_ld(planes):
+    """leading dimension (elements per row) of a packed plane pair"""
+    return planes[0].stride(0) // 2
+
+
+def planes_to_f32(planes):
+    """hi + lo as a float32 tensor [rows, ld] (torch arithmetic: tests / inspection)"""
+    hi, lo = planes
+    rows = hi.shape[0]
+    return (hi.contiguous().view(torch.bfloat16).float() + lo.contiguous().view(torch.bfloat16).float()).reshape(rows, -1)
+
+
 def split_planes3(ctx, src, hi, lo):
     check(lib.pp_split_planes_bf16x3(ctx.handle, src.numel(), _ptr(src), _ptr(hi), _ptr(lo)), ctx.handle, "pp_split_planes_bf16x3")
 
@@ -134,15 +155,73 @@ def row_block_list(ctx, x, cols, flags=None, blocks=None):
     return flags, blocks
 
 
+def row_block_list_planes(ctx, planes, cols, flags, blocks):
+    """pp_row_block_list_planes: the same scan of a tensor stored as bf16 (hi, lo) planes [rows, ld]"""
+    hi, lo = planes
+    rows = hi.shape[0]
+    check(lib.pp_row_block_list_planes(ctx.handle, _ptr(hi), _ptr(lo), rows, planes_ld(planes), int(cols), _ptr(flags), _ptr(blocks)), ctx.handle,
+          "pp_row_block_list_planes")
+    return flags, blocks
+
+
+def _set_epilogue_planes(ctx, add_planes, mask_hi):
+    if add_planes is not None or mask_hi is not None:
+        ah, al = add_planes if add_planes is not None else (None, None)
+        check(lib.pp_ctx_set_epilogue_planes(ctx.handle, _ptr(ah), _ptr(al), _ptr(mask_hi)), ctx.handle, "pp_ctx_set_epilogue_planes")
+
+
+def tview(t=None, planes=None):
+    """pp_tview of a float32 tensor and / or a (hi, lo) plane pair; None, None = the NULL view"""
+    v = TView()
+    v.f32 = t.data_ptr() if t is not None else None
+    v.hi = planes[0].data_ptr() if planes is not None else None
+    v.lo = planes[1].data_ptr() if planes is not None else None
+    v._keep = (t, planes)
+    return v
+
+
+def _numel(v):
+    t, planes = v._keep
+    return (t if t is not None else planes[0]).numel()
+
+
+def add_n_v(ctx, a, b, c, out):
+    null = TView()
+    check(lib.pp_add_n_v(ctx.handle, _numel(a), C.byref(a), C.byref(b if b is not None else null), C.byref(c if c is not None else null),
+                         C.byref(out)), ctx.handle, "pp_add_n_v")
+
+
+def relu_fwd_v(ctx, x, y):
+    check(lib.pp_relu_fwd_v(ctx.handle, _numel(x), C.byref(x), C.byref(y)), ctx.handle, "pp_relu_fwd_v")
+
+
+def upsample_add_fwd_v(ctx, n_img, sh, sw, th, tw, c, src, other, out):
+    null = TView()
+    check(lib.pp_upsample_nearest_add_fwd_v(ctx.handle, n_img, sh, sw, th, tw, c, C.byref(src), C.byref(other if other is not None else null),
+                                            C.byref(out)), ctx.handle, "pp_upsample_nearest_add_fwd_v")
+
+
+def upsample_add_bwd_v(ctx, n_img, sh, sw, th, tw, c, dtarget, base, dsrc):
+    null = TView()
+    check(lib.pp_upsample_nearest_add_bwd_v(ctx.handle, n_img, sh, sw, th, tw, c, C.byref(dtarget), C.byref(base if base is not None else null),
+                                            C.byref(dsrc)), ctx.handle, "pp_upsample_nearest_add_bwd_v")
+
+
+def merge_planes3(ctx, planes, dst):
+    check(lib.pp_merge_planes_bf16x3(ctx.handle, dst.numel(), _ptr(planes[0]), _ptr(planes[1]), _ptr(dst)), ctx.handle, "pp_merge_planes_bf16x3")
+
+
 def _set_skip(ctx, skip):
     if skip is not None:
         check(lib.pp_ctx_set_row_block_skip(ctx.handle, _ptr(skip[0]), _ptr(skip[1])), ctx.handle, "pp_ctx_set_row_block_skip")
 
 
-def conv_fwd3(ctx, d, x, w_hi, w_lo, bias, residual, relu, y, x_planes=None, y_planes=None, x_capture=None):
-    """x_capture = (hi, lo): the launch also writes the bf16 split of x (pp_ctx_set_split_capture)."""
+def conv_fwd3(ctx, d, x, w_hi, w_lo, bias, residual, relu, y, x_planes=None, y_planes=None, x_capture=None, res_planes=None):
+    """x_capture = (hi, lo): the launch also writes the bf16 split of x (pp_ctx_set_split_capture).
+    res_planes = (hi, lo): the residual as planes (pp_ctx_set_epilogue_planes; `residual` must then be None)."""
     _set_capture(ctx, x_capture)
-    ld_res = residual.stride(0) if residual is not None else 0
+    _set_epilogue_planes(ctx, res_planes, None)
+    ld_res = residual.stride(0) if residual is not None else (planes_ld(res_planes) if res_planes is not None else 0)
     xh, xl = x_planes if x_planes is not None else (None, None)
     yh, yl = y_planes if y_planes is not None else (None, None)
     check(lib.pp_conv2d_nhwc_fwd_bf16x3(ctx.handle, C.byref(d), _ptr(x), _ptr(xh), _ptr(xl), _ptr(w_hi), _ptr(w_lo), _ptr(bias),
@@ -150,13 +229,16 @@ def conv_fwd3(ctx, d, x, w_hi, w_lo, bias, residual, relu, y, x_planes=None, y_p
           "pp_conv2d_nhwc_fwd_bf16x3")
 
 
-def conv_bwd_data3(ctx, d, dy, w_hi, w_lo, addend, relu_src, dx, dy_planes=None, dx_planes=None, dy_capture=None, dy_skip=None):
+def conv_bwd_data3(ctx, d, dy, w_hi, w_lo, addend, relu_src, dx, dy_planes=None, dx_planes=None, dy_capture=None, dy_skip=None,
+                   addend_planes=None, relu_src_hi=None):
     """dy_capture = (hi, lo): the launch also writes the bf16 split of dy (pp_ctx_set_split_capture).
-    dy_skip = (flags, list) from row_block_list(dy): tiles that only see zero blocks of dy skip their reduction."""
+    dy_skip = (flags, list) from row_block_list(dy): tiles that only see zero blocks of dy skip their reduction.
+    addend_planes = (hi, lo) / relu_src_hi = hi plane: those epilogue operands as planes (pp_ctx_set_epilogue_planes)."""
     _set_capture(ctx, dy_capture)
     _set_skip(ctx, dy_skip)
-    ld_add = addend.stride(0) if addend is not None else 0
-    ld_rs = relu_src.stride(0) if relu_src is not None else 0
+    _set_epilogue_planes(ctx, addend_planes, relu_src_hi)
+    ld_add = addend.stride(0) if addend is not None else (planes_ld(addend_planes) if addend_planes is not None else 0)
+    ld_rs = relu_src.stride(0) if relu_src is not None else (relu_src_hi.stride(0) // 2 if relu_src_hi is not None else 0)
     dh, dl = dy_planes if dy_planes is not None else (None, None)
     xh, xl = dx_planes if dx_planes is not None else (None, None)
     check(lib.pp_conv2d_nhwc_bwd_data_bf16x3(ctx.handle, C.byref(d), _ptr(dy), _ptr(dh), _ptr(dl), _ptr(w_hi), _ptr(w_lo), _ptr(addend),

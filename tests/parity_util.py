@@ -36,7 +36,7 @@ def engine_relu_masks(eng):
     for name, act in eng.acts.items():
         if not act.relu:
             continue
-        t = act.t[:, : act.C].detach().cpu()
+        t = act.f32(eng.ctx)[:, : act.C].detach().cpu()
         per_level, r0 = [], 0
         for (h, w) in act.shapes:
             n = act.n_img * h * w

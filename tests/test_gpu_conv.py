@@ -166,8 +166,8 @@ def test_conv_fwd_bwd(ctx, case):
     assert rel_err(db.cpu().numpy()[:cout], db_ref) < 5e-5
     # operands from pre-split planes
     xd, gd = _cat_rows(xs), _cat_rows(gys, ld_y)
-    xh, xl = torch.zeros_like(xd, dtype=torch.int16), torch.zeros_like(xd, dtype=torch.int16)
-    gh, gl = torch.zeros_like(gd, dtype=torch.int16), torch.zeros_like(gd, dtype=torch.int16)
+    xh, xl = ops.new_planes(xd.shape[0], xd.shape[1])
+    gh, gl = ops.new_planes(gd.shape[0], gd.shape[1])
     ops.split_planes3(ctx, xd, xh, xl)
     ops.split_planes3(ctx, gd, gh, gl)
     dw2 = torch.zeros_like(dw); db2 = torch.zeros_like(db)
@@ -281,16 +281,16 @@ def test_conv_bf16x3_fwd_bwd_data(ctx, case):
     assert e < 1e-4, e
     # same conv with the gathered operand pre-split into (hi, lo) planes: same products; the launch may take a different
     # kernel (tap order), so equal up to f32 summation order
-    xh, xl = torch.zeros_like(x, dtype=torch.int16), torch.zeros_like(x, dtype=torch.int16)
+    xh, xl = ops.new_planes(x.shape[0], x.shape[1])
     ops.split_planes3(ctx, x, xh, xl)
-    assert rel_err((xh.view(torch.bfloat16).float() + xl.view(torch.bfloat16).float()).cpu().numpy(), x.cpu().numpy()) < 2e-5
+    assert rel_err(ops.planes_to_f32((xh, xl)).cpu().numpy(), x.cpu().numpy()) < 2e-5
     y2 = torch.full_like(y, float("nan"))
-    yh, yl = torch.zeros_like(y, dtype=torch.int16), torch.zeros_like(y, dtype=torch.int16)
+    yh, yl = ops.new_planes(y.shape[0], y.shape[1])
     ops.conv_fwd3(ctx, d, None, fh, fl, bd.cuda(), _cat_rows(res, ld_y), True, y2, x_planes=(xh, xl), y_planes=(yh, yl))
     assert rel_err(y2[:, :cout].cpu().numpy(), y[:, :cout].cpu().numpy()) < 2e-6
     # split capture: the launch also emits the bf16 split of its f32 operand (from the loop's registers where the tap-row
     # reuse kernel runs, by a separate pass elsewhere); the result itself does not change
-    ch, cl = torch.full_like(xh, 0x7fc0), torch.full_like(xl, 0x7fc0)
+    ch, cl = ops.new_planes(xh.shape[0], xh.shape[1] * xh.shape[2], fill=0x7fc0)
     y3 = torch.full_like(y, float("nan"))
     ops.conv_fwd3(ctx, d, x, fh, fl, bd.cuda(), _cat_rows(res, ld_y), True, y3, x_capture=(ch, cl))
     assert torch.equal(torch.nan_to_num(y3), torch.nan_to_num(y))
@@ -299,9 +299,10 @@ def test_conv_bf16x3_fwd_bwd_data(ctx, case):
     ops.conv_fwd3(ctx, d, x, fh, fl, bd.cuda(), _cat_rows(res, ld_y), True, y3)  # the capture is one-shot
     assert torch.equal(torch.nan_to_num(y3), torch.nan_to_num(y))
     # ... and the epilogue's pre-split copy of the output is exactly what the split kernel makes of it
-    wh, wl = torch.zeros_like(yh), torch.zeros_like(yl)
+    wh, wl = ops.new_planes(y2.shape[0], y2.shape[1])
     ops.split_planes3(ctx, torch.nan_to_num(y2), wh, wl)
-    assert torch.equal(yh[:, :cout], wh[:, :cout]) and torch.equal(yl[:, :cout], wl[:, :cout])
+    flat = lambda t: t.reshape(t.shape[0], -1)
+    assert torch.equal(flat(yh)[:, :cout], flat(wh)[:, :cout]) and torch.equal(flat(yl)[:, :cout], flat(wl)[:, :cout])
     # bwd-data against float64 autograd
     xg = [t.clone().requires_grad_(True) for t in xs]
     wt = torch.as_tensor(w, dtype=torch.float64)
@@ -324,19 +325,19 @@ def test_conv_bf16x3_fwd_bwd_data(ctx, case):
     want = torch.cat([((g + a) * (r > 0)).reshape(-1, cin) for g, a, r in zip(gx_ref, addend, rsrc)], dim=0).numpy()
     e = rel_err(dx.cpu().numpy(), want)
     assert e < 1e-4, e
-    gh, gl = torch.zeros_like(gy, dtype=torch.int16), torch.zeros_like(gy, dtype=torch.int16)
+    gh, gl = ops.new_planes(gy.shape[0], gy.shape[1])
     ops.split_planes3(ctx, gy, gh, gl)
     cred = (cout + 31) // 32 * 32
-    ch, cl = torch.full_like(gh, 0x7fc0), torch.full_like(gl, 0x7fc0)
+    ch, cl = ops.new_planes(gh.shape[0], gh.shape[1] * gh.shape[2], fill=0x7fc0)
     dx3 = torch.full_like(dx, float("nan"))
     ops.conv_bwd_data3(ctx, d, gy, dh, dl, _cat_rows(addend), _cat_rows(rsrc), dx3, dy_capture=(ch, cl))
     assert torch.equal(dx3, dx)
-    assert torch.equal(ch[:, :cred], gh[:, :cred]) and torch.equal(cl[:, :cred], gl[:, :cred])
+    assert torch.equal(flat(ch)[:, :cred], flat(gh)[:, :cred]) and torch.equal(flat(cl)[:, :cred], flat(gl)[:, :cred])
     dx2 = torch.full_like(dx, float("nan"))
-    xh2, xl2 = torch.zeros_like(dx, dtype=torch.int16), torch.zeros_like(dx, dtype=torch.int16)
+    xh2, xl2 = ops.new_planes(dx.shape[0], dx.shape[1])
     ops.conv_bwd_data3(ctx, d, None, dh, dl, _cat_rows(addend), _cat_rows(rsrc), dx2, dy_planes=(gh, gl), dx_planes=(xh2, xl2))
     assert rel_err(dx2.cpu().numpy(), dx.cpu().numpy()) < 2e-6
-    wh, wl = torch.zeros_like(xh2), torch.zeros_like(xl2)
+    wh, wl = ops.new_planes(dx2.shape[0], dx2.shape[1])
     ops.split_planes3(ctx, dx2, wh, wl)
     assert torch.equal(xh2, wh) and torch.equal(xl2, wl)
 
@@ -381,8 +382,8 @@ def test_conv_bf16x3_bwd_weight(ctx, case):
     assert rel_err(db.cpu().numpy()[:cout], db_ref) < 5e-5
     # operands from pre-split planes
     xd, gd = _cat_rows(xs), _cat_rows(gys, ld_y)
-    xh, xl = torch.zeros_like(xd, dtype=torch.int16), torch.zeros_like(xd, dtype=torch.int16)
-    gh, gl = torch.zeros_like(gd, dtype=torch.int16), torch.zeros_like(gd, dtype=torch.int16)
+    xh, xl = ops.new_planes(xd.shape[0], xd.shape[1])
+    gh, gl = ops.new_planes(gd.shape[0], gd.shape[1])
     ops.split_planes3(ctx, xd, xh, xl)
     ops.split_planes3(ctx, gd, gh, gl)
     dw2 = torch.zeros_like(dw); db2 = torch.zeros_like(db)
@@ -460,9 +461,9 @@ def test_conv_bf16x3_split_k(ctx, splits, monkeypatch):
         y3, dx3 = run()
         assert torch.equal(y2, y3) and torch.equal(dx2, dx3)
         # split capture under split-K: every (kernel row, channel chunk) group belongs to exactly one split
-        xh, xl = torch.zeros_like(x, dtype=torch.int16), torch.zeros_like(x, dtype=torch.int16)
+        xh, xl = ops.new_planes(x.shape[0], x.shape[1])
         ops.split_planes3(ctx, x, xh, xl)
-        ch, cl = torch.full_like(xh, 0x7fc0), torch.full_like(xl, 0x7fc0)
+        ch, cl = ops.new_planes(xh.shape[0], xh.shape[1] * xh.shape[2], fill=0x7fc0)
         y4 = torch.full((rows, ld_y), float("nan"), dtype=torch.float32, device="cuda")
         ops.conv_fwd3(ctx, d, x, fh, fl, bias, res, True, y4, x_capture=(ch, cl))
         assert torch.equal(y4[:, :cout], y2) and torch.equal(ch, xh) and torch.equal(cl, xl)

@@ -82,9 +82,9 @@ def test_forward_small_vs_oracle_f64(ctx, shape, mode):
     # intermediate pins
     for name, act in (("C3", eng.C3), ("C4", eng.C4), ("C5", eng.C5)):
         want = ref[name].permute(0, 2, 3, 1).reshape(-1, act.C).numpy()
-        assert rel(act.t.cpu().numpy(), want) < TOL, name
+        assert rel(act.f32(eng.ctx)[:, : act.C].cpu().numpy(), want) < TOL, name
     pyr_want = np.concatenate([ref[n].permute(0, 2, 3, 1).reshape(-1, 256).numpy() for n in ("P3", "P4", "P5")])
-    assert rel(eng.pyr.t.cpu().numpy(), pyr_want) < TOL
+    assert rel(eng.pyr.f32(eng.ctx).cpu().numpy(), pyr_want) < TOL
     reg_raw = eng.out_box.cpu().numpy()
     # the head-output bar, per row (every anchor's vector against its own magnitude: tests/parity_util.py)
     assert_rows_within(reg_raw, ref["3Dbox"].numpy(), "3Dbox", TOL)
@@ -144,6 +144,7 @@ def test_split_capture_training_step_matches_default(ctx, monkeypatch):
     Wt = arch.init_weights(C, seed=15)
     x = torch.from_numpy(synth_input(rng, B, H, W)).cuda()
     got = {}
+    monkeypatch.setenv("PP_PLANES", "0")  # (split capture belongs to the float32-storage mode)
     for cap in ("0", "1"):
         monkeypatch.setenv("PP_CAPTURE", cap)
         eng = Engine(ctx, C, B, H, W, weights=Wt, train=True, conv_mode="bf16x3")
@@ -278,15 +279,20 @@ def test_data_parallel_path_single_rank_nccl(ctx):
         dist.destroy_process_group()
 
 
-def test_two_rank_data_parallel_equals_global_batch(ctx, tmp_path):
+def test_two_rank_data_parallel_equals_global_batch(ctx, tmp_path, monkeypatch):
     """two ranks with two images each (count exchange + bucketed gradient all-reduce, gloo here because the
     ranks share the box's one GPU) must take the step a single process takes on the global batch of four: same positive
-    counts, same summed gradient, same weights after clipnorm-Adam, and rank-wise loss shares that add up."""
+    counts, same summed gradient, same weights after clipnorm-Adam, and rank-wise loss shares that add up.
+    Split-K is off on both sides: its split count depends on the batch, a different summation order moves an activation
+    by an ulp, and a ReLU input that is zero to rounding may then land on the other side of the kink (tools/debug_splitk.py:
+    up to 2e-2 per gradient tensor, in either storage mode) -- nothing to do with the exchange this test is about.  Without
+    it every image's rows are computed in the same order whatever the batch, and the comparison is tight."""
     import os
     import subprocess
     import sys
     from pyrapose_amd.engine import Engine
     from tests.dp_worker import global_batch
+    monkeypatch.setenv("PP_SPLITK_MB", "0")
     B, H, W, C, Wt, x, tg = global_batch()
     eng = Engine(ctx, C, B, H, W, weights=Wt, train=True)
     eng.train_step(torch.from_numpy(x).cuda(), [torch.from_numpy(a).cuda() for a in tg])

@@ -1,0 +1,290 @@
+"""GPU: the planes-only storage format of the bf16x3 path (activations / gradients as bf16 (hi, lo) planes, value = hi + lo):
+every kernel variant that reads or writes planes -- gathered operand, output tile, residual / addend / ReLU source of the
+epilogues, split-K finish, stride-2 parity classes, row-list sparse backward, weight gradient over a block list, the
+pointwise ops on tensor views -- against the SAME launch on float32 tensors.  The products are identical (same hi, lo);
+a value read back from planes is within 2^-17 of the float32 it was split from, so results agree to ~1e-5 of the tensor's
+magnitude; where no operand is read back from planes they agree to f32 summation order."""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_gpu_conv import BF3_CASES, WG3_CASES, _cat_rows, _device_weight, _setup, rel_err, tf_same
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from pyrapose_amd.runtime import default_context
+    return default_context()
+
+
+def split(ctx, t):
+    from pyrapose_amd import ops
+    hi, lo = ops.new_planes(t.shape[0], t.shape[1])
+    ops.split_planes3(ctx, t, hi, lo)
+    return hi, lo
+
+
+def merged(pl):
+    from pyrapose_amd import ops
+    return ops.planes_to_f32(pl)
+
+
+def nan_planes(like):
+    from pyrapose_amd import ops
+    return ops.new_planes(like.shape[0], like.shape[1], fill=0x7fc0)
+
+
+def raw(pl):
+    """the two planes as plain [rows, ld] int16 matrices (copies)"""
+    return pl[0].reshape(pl[0].shape[0], -1), pl[1].reshape(pl[1].shape[0], -1)
+
+
+def _geometry(case):
+    from pyrapose_amd import ops
+    name, B, shapes, cin, cout, k, stride, pad, ld_y, xs, w, bias = _setup(case, seed=3)
+    out_shapes = []
+    for (h, ww) in shapes:
+        if pad == "same":
+            out_shapes.append((-(-h // stride), -(-ww // stride)))
+        else:
+            out_shapes.append(((h + 2 * pad - k) // stride + 1, (ww + 2 * pad - k) // stride + 1))
+    if pad == "same":
+        pt, pl = tf_same(shapes[0][0], k, stride)[0], tf_same(shapes[0][1], k, stride)[0]
+    else:
+        pt = pl = pad
+    ld_y = (ld_y or cout)
+    ld_y = (ld_y + 31) // 32 * 32  # what the engine uses in bf16x3 mode (planes need ld % 8 == 0)
+    wd, ld_w = _device_weight(w, cout)
+    d = ops.make_conv_desc(B, shapes, out_shapes, cin, cout, k, stride, pt, pl, cin, ld_y, ld_w)
+    taps = k * k
+    u16 = dict(dtype=torch.int16, device="cuda")
+    fh, fl = torch.zeros((taps, cout, cin), **u16), torch.zeros((taps, cout, cin), **u16)
+    cred = (cout + 31) // 32 * 32
+    dh, dl = torch.zeros((taps, cin, cred), **u16), torch.zeros((taps, cin, cred), **u16)
+    return d, wd, ld_w, ld_y, cred, xs, bias, out_shapes, B, cin, cout
+
+
+@pytest.mark.parametrize("case", BF3_CASES, ids=[c[0] for c in BF3_CASES])
+def test_planes_only_fwd_and_bwd_data(ctx, case):
+    from pyrapose_amd import ops
+    d, wd, ld_w, ld_y, cred, xs, bias, out_shapes, B, cin, cout = _geometry(case)
+    rng = np.random.default_rng(2)
+    taps = d.kh * d.kw
+    u16 = dict(dtype=torch.int16, device="cuda")
+    fh, fl = torch.zeros((taps, cout, cin), **u16), torch.zeros((taps, cout, cin), **u16)
+    dh, dl = torch.zeros((taps, cin, cred), **u16), torch.zeros((taps, cin, cred), **u16)
+    ops.conv_split_weights3(ctx, d, wd, fh, fl, dh, dl)
+    x = _cat_rows(xs)
+    rows_out = sum(B * h * w for h, w in out_shapes)
+    res = torch.zeros((rows_out, ld_y), dtype=torch.float32, device="cuda")
+    res[:, :cout] = torch.as_tensor(rng.standard_normal((rows_out, cout)), dtype=torch.float32).cuda()
+    bd = torch.zeros((ld_w,), dtype=torch.float32)
+    bd[:cout] = torch.as_tensor(bias, dtype=torch.float32)
+    bd = bd.cuda()
+    # ---- forward: f32 everywhere vs planes everywhere
+    y = torch.full((rows_out, ld_y), float("nan"), dtype=torch.float32, device="cuda")
+    ops.conv_fwd3(ctx, d, x, fh, fl, bd, res, True, y)
+    xp, rp = split(ctx, x), split(ctx, res)
+    yp = nan_planes(y)
+    ops.conv_fwd3(ctx, d, None, fh, fl, bd, None, True, None, x_planes=xp, y_planes=yp, res_planes=rp)
+    got = merged(yp)[:, :cout]
+    scale = float(y[:, :cout].abs().max())
+    assert float((got - y[:, :cout]).abs().max()) <= 2e-5 * scale
+    # the residual given as f32, output as planes only: exactly the split of the f32 output of the same kernel
+    yp2 = nan_planes(y)
+    y2 = torch.full_like(y, float("nan"))
+    ops.conv_fwd3(ctx, d, None, fh, fl, bd, res, True, y2, x_planes=xp, y_planes=yp2)
+    yp3 = nan_planes(y)
+    ops.conv_fwd3(ctx, d, None, fh, fl, bd, res, True, None, x_planes=xp, y_planes=yp3)
+    (a_h, a_l), (b_h, b_l) = raw(yp2), raw(yp3)
+    assert torch.equal(a_h[:, :cout], b_h[:, :cout]) and torch.equal(a_l[:, :cout], b_l[:, :cout])
+    wh, wl = raw(split(ctx, torch.nan_to_num(y2)))
+    assert torch.equal(b_h[:, :cout], wh[:, :cout]) and torch.equal(b_l[:, :cout], wl[:, :cout])
+    # ---- bwd-data: dy, addend, ReLU source as planes, dx as planes only
+    gy = torch.zeros((rows_out, ld_y), dtype=torch.float32, device="cuda")
+    gy[:, :cout] = torch.as_tensor(rng.standard_normal((rows_out, cout)), dtype=torch.float32).cuda()
+    add = torch.as_tensor(rng.standard_normal(tuple(x.shape)), dtype=torch.float32).cuda()
+    rsrc = torch.relu(torch.as_tensor(rng.standard_normal(tuple(x.shape)), dtype=torch.float32)).cuda()  # a post-ReLU activation
+    dx = torch.full_like(x, float("nan"))
+    ops.conv_bwd_data3(ctx, d, gy, dh, dl, add, rsrc, dx)
+    gp, ap, mp = split(ctx, gy), split(ctx, add), split(ctx, rsrc)
+    dxp = nan_planes(dx)
+    ops.conv_bwd_data3(ctx, d, None, dh, dl, None, None, None, dy_planes=gp, dx_planes=dxp, addend_planes=ap, relu_src_hi=mp[0])
+    got = merged(dxp)
+    scale = float(dx.abs().max())
+    assert float((got - dx).abs().max()) <= 2e-5 * scale
+    assert torch.equal(got == 0, dx == 0) or float(((got == 0) != (dx == 0)).float().mean()) < 1e-4  # the same ReLU mask
+    # without addend / mask
+    dx0 = torch.full_like(x, float("nan"))
+    ops.conv_bwd_data3(ctx, d, gy, dh, dl, None, None, dx0)
+    dxp0 = nan_planes(dx)
+    ops.conv_bwd_data3(ctx, d, None, dh, dl, None, None, None, dy_planes=gp, dx_planes=dxp0)
+    assert float((merged(dxp0) - dx0).abs().max()) <= 2e-5 * max(float(dx0.abs().max()), 1e-30)
+
+
+@pytest.mark.parametrize("splits", [3])
+def test_planes_only_split_k(ctx, splits, monkeypatch):
+    from pyrapose_amd import ops
+    rng = np.random.default_rng(11)
+    B, H, W, cin, cout, k = 2, 9, 13, 128, 96, 3
+    ld_y = 96
+    d = ops.make_conv_desc(B, [(H, W)], [(H, W)], cin, cout, k, 1, 1, 1, cin, ld_y, 96)
+    rows = B * H * W
+    x = torch.as_tensor(rng.standard_normal((rows, cin)), dtype=torch.float32).cuda()
+    w = torch.as_tensor(rng.standard_normal((k * k * cin, 96)) * 0.05, dtype=torch.float32).cuda()
+    bias = torch.as_tensor(rng.standard_normal((96,)), dtype=torch.float32).cuda()
+    res = torch.as_tensor(rng.standard_normal((rows, ld_y)), dtype=torch.float32).cuda()
+    i16 = dict(dtype=torch.int16, device="cuda")
+    fh, fl = torch.zeros((k * k, cout, cin), **i16), torch.zeros((k * k, cout, cin), **i16)
+    dh, dl = torch.zeros((k * k, cin, ld_y), **i16), torch.zeros((k * k, cin, ld_y), **i16)
+    ops.conv_split_weights3(ctx, d, w, fh, fl, dh, dl)
+    gy = torch.as_tensor(rng.standard_normal((rows, ld_y)), dtype=torch.float32).cuda()
+    add = torch.as_tensor(rng.standard_normal((rows, cin)), dtype=torch.float32).cuda()
+    msk = torch.relu(torch.as_tensor(rng.standard_normal((rows, cin)), dtype=torch.float32)).cuda()
+    xp, rp, gp, ap, mp = (split(ctx, t) for t in (x, res, gy, add, msk))
+
+    def run():
+        yp, dxp = nan_planes(res), nan_planes(x)
+        ops.conv_fwd3(ctx, d, None, fh, fl, bias, None, True, None, x_planes=xp, y_planes=yp, res_planes=rp)
+        ops.conv_bwd_data3(ctx, d, None, dh, dl, None, None, None, dy_planes=gp, dx_planes=dxp, addend_planes=ap, relu_src_hi=mp[0])
+        torch.cuda.synchronize()
+        return merged(yp), merged(dxp)
+
+    monkeypatch.setenv("PP_CONV3_SPLITS", "1")
+    y1, dx1 = run()
+    ctx.set_workspace(splits * rows * max(ld_y, cin) * 4)
+    try:
+        monkeypatch.setenv("PP_CONV3_SPLITS", str(splits))
+        ctx.workspace.fill_(float("nan"))
+        y2, dx2 = run()
+        y3, dx3 = run()
+        assert torch.equal(y2, y3) and torch.equal(dx2, dx3)  # deterministic
+    finally:
+        ctx.set_workspace(0)
+    assert float((y2 - y1).abs().max()) <= 2e-5 * float(y1.abs().max())
+    assert float((dx2 - dx1).abs().max()) <= 2e-5 * float(dx1.abs().max())
+    assert bool(y1.isfinite().all()) and bool(dx1.isfinite().all()) and float(y1.abs().max()) > 0
+
+
+@pytest.mark.parametrize("frac", [0.0, 0.03])
+def test_planes_only_row_block_skip(ctx, frac):
+    """sparse backward (3D-box head) on planes: block list from planes, row-list bwd-data and block-list bwd-weight"""
+    from pyrapose_amd import ops
+    rng = np.random.default_rng(17)
+    B, shapes, cin, cout, k = 2, [(20, 26), (10, 13), (5, 7)], 128, 64, 3
+    rows = sum(B * h * w for h, w in shapes)
+    d = ops.make_conv_desc(B, shapes, shapes, cin, cout, k, 1, 1, 1, cin, cout, cout)
+    x = torch.as_tensor(rng.standard_normal((rows, cin)), dtype=torch.float32).cuda()
+    w = torch.as_tensor(rng.standard_normal((k * k * cin, cout)) * 0.05, dtype=torch.float32).cuda()
+    dy = torch.zeros((rows, cout), dtype=torch.float32, device="cuda")
+    live = torch.as_tensor(rng.uniform(size=rows) < frac).cuda()
+    dy[live] = torch.as_tensor(rng.standard_normal((int(live.sum()), cout)), dtype=torch.float32).cuda()
+    i16 = dict(dtype=torch.int16, device="cuda")
+    fh, fl = torch.zeros((k * k, cout, cin), **i16), torch.zeros((k * k, cout, cin), **i16)
+    dh, dl = torch.zeros((k * k, cin, cout), **i16), torch.zeros((k * k, cin, cout), **i16)
+    ops.conv_split_weights3(ctx, d, w, fh, fl, dh, dl)
+    flags, blocks = ops.row_block_list(ctx, dy, cout)
+    gp, xp = split(ctx, dy), split(ctx, x)
+    f2, b2 = torch.zeros_like(flags), torch.zeros_like(blocks)
+    ops.row_block_list_planes(ctx, gp, cout, f2, b2)
+    nb = (rows + 31) // 32
+    assert torch.equal(f2[:nb], flags[:nb]) and torch.equal(b2[: nb + 1], blocks[: nb + 1])
+    add = torch.as_tensor(rng.standard_normal((rows, cin)), dtype=torch.float32).cuda()
+    msk = torch.relu(torch.as_tensor(rng.standard_normal((rows, cin)), dtype=torch.float32)).cuda()
+    ap, mp = split(ctx, add), split(ctx, msk)
+    dx0 = torch.full((rows, cin), float("nan"), device="cuda")
+    ops.conv_bwd_data3(ctx, d, dy, dh, dl, add, msk, dx0)
+    dxp = nan_planes(dx0)
+    ops.conv_bwd_data3(ctx, d, None, dh, dl, None, None, None, dy_planes=gp, dx_planes=dxp, dy_skip=(f2, b2), addend_planes=ap,
+                       relu_src_hi=mp[0])
+    assert float((merged(dxp) - dx0).abs().max()) <= 2e-5 * float(dx0.abs().max())
+    assert not bool(f2[nb: 2 * nb].all())  # some blocks were filled, not computed
+    dw0, dw1 = torch.zeros_like(w), torch.zeros_like(w)
+    db0, db1 = torch.zeros((cout,), device="cuda"), torch.zeros((cout,), device="cuda")
+    ops.conv_bwd_weight3(ctx, d, x, dy, dw0, db0)
+    ops.conv_bwd_weight3(ctx, d, None, None, dw1, db1, x_planes=xp, dy_planes=gp, dy_skip=(f2, b2))
+    scale = max(float(dw0.abs().max()), 1e-30)
+    assert float((dw0 - dw1).abs().max()) <= 2e-6 * scale
+    assert float((db0 - db1).abs().max()) <= 2e-5 * max(float(db0.abs().max()), 1e-30)
+    if frac == 0.0:
+        assert not dw1.any() and not db1.any()
+
+
+def test_pointwise_ops_on_views(ctx):
+    from pyrapose_amd import ops
+    rng = np.random.default_rng(5)
+    B, C = 2, 64
+    for (sh, sw, th, tw) in ((3, 4, 6, 8), (17, 23, 34, 45)):
+        src = torch.as_tensor(rng.standard_normal((B * sh * sw, C)), dtype=torch.float32).cuda()
+        oth = torch.as_tensor(rng.standard_normal((B * th * tw, C)), dtype=torch.float32).cuda()
+        want = torch.empty_like(oth)
+        ops.upsample_add_fwd(ctx, B, sh, sw, th, tw, C, src, oth, want)
+        sp, op_ = split(ctx, src), split(ctx, oth)
+        outp = nan_planes(oth)
+        outf = torch.empty_like(oth)
+        ops.upsample_add_fwd_v(ctx, B, sh, sw, th, tw, C, ops.tview(None, sp), ops.tview(None, op_), ops.tview(outf, outp))
+        assert float((outf - want).abs().max()) <= 2e-5 * float(want.abs().max())
+        wh, wl = split(ctx, outf)
+        assert torch.equal(outp[0], wh) and torch.equal(outp[1], wl)  # both output formats hold the same values
+        g = torch.as_tensor(rng.standard_normal((B * th * tw, C)), dtype=torch.float32).cuda()
+        gs_want = torch.empty_like(src)
+        ops.upsample_add_bwd(ctx, B, sh, sw, th, tw, C, g, None, gs_want)
+        gsp = nan_planes(src)
+        ops.upsample_add_bwd_v(ctx, B, sh, sw, th, tw, C, ops.tview(None, split(ctx, g)), None, ops.tview(None, gsp))
+        assert float((merged(gsp) - gs_want).abs().max()) <= 2e-5 * float(gs_want.abs().max())
+    a = torch.as_tensor(rng.standard_normal((1000, 8)), dtype=torch.float32).cuda()
+    b = torch.as_tensor(rng.standard_normal((1000, 8)), dtype=torch.float32).cuda()
+    outp = nan_planes(a)
+    ops.add_n_v(ctx, ops.tview(a), ops.tview(None, split(ctx, b)), None, ops.tview(None, outp))
+    assert float((merged(outp) - (a + b)).abs().max()) <= 2e-5 * float((a + b).abs().max())
+    out = torch.empty_like(a)
+    ops.add_n_v(ctx, ops.tview(a), ops.tview(b), ops.tview(a), ops.tview(out))
+    assert torch.equal(out, (a + b) + a)
+    yp = nan_planes(a)
+    ops.relu_fwd_v(ctx, ops.tview(None, split(ctx, a)), ops.tview(None, yp))
+    assert torch.equal(merged(yp) > 0, a > 0)
+    back = torch.empty_like(a)
+    ops.merge_planes3(ctx, split(ctx, a), back)
+    assert float((back - a).abs().max()) <= 2 ** -16 * float(a.abs().max())
+    with pytest.raises(ValueError):
+        ops.add_n_v(ctx, ops.tview(a, split(ctx, a)), None, None, ops.tview(out))  # an input view is f32 OR planes
+    with pytest.raises(ValueError):  # two separate planes are not the packed layout
+        sep = (torch.zeros_like(a, dtype=torch.int16), torch.zeros_like(a, dtype=torch.int16))
+        ops.split_planes3(ctx, a, sep[0], sep[1])
+
+
+@pytest.mark.parametrize("mode", ["1", "0"])
+def test_engine_planes_mode_matches_f32_storage(ctx, mode, monkeypatch):
+    """The whole training step with planes-only storage (default) vs float32 storage with in-loop splits (PP_PLANES=0): same
+    products; residual / addend reads differ by 2^-17 -> every output and the gradient agree to ~1e-5."""
+    from pyrapose_amd import arch
+    from pyrapose_amd.engine import Engine
+    from tests.test_gpu_model import random_targets, synth_input
+    B, H, W, C = 2, 96, 128, 5
+    rng = np.random.default_rng(71)
+    Wt = arch.init_weights(C, seed=72)
+    x = torch.from_numpy(synth_input(rng, B, H, W)).cuda()
+    monkeypatch.setenv("PP_PLANES", mode)
+    eng = Engine(ctx, C, B, H, W, weights=Wt, train=True, conv_mode="bf16x3")
+    assert eng.po == (mode == "1")
+    if mode == "1":
+        assert eng.C3.t is None and eng.C3.pl is not None and eng.pyr.t is None and eng.reg_out.t is not None
+    tg = [torch.from_numpy(a).cuda() for a in random_targets(rng, B, eng.N, eng.M3, C, pos_frac=0.02)]
+    eng.set_targets(*tg)
+    eng.forward(x)
+    eng.loss_and_backward()
+    torch.cuda.synchronize()
+    key = (eng.reg_out.t[:, : eng.reg_out.C].clone(), eng.cls_out.t[:, : eng.cls_out.C].clone(), eng.C5.f32(eng.ctx).clone(),
+           eng.params.grad.clone(), eng.losses())
+    store = test_engine_planes_mode_matches_f32_storage.__dict__.setdefault("runs", {})
+    store[mode] = key
+    if len(store) == 2:
+        a, b = store["1"], store["0"]
+        for i in range(3):
+            assert float((a[i] - b[i]).abs().max()) <= 3e-5 * float(b[i].abs().max()), i
+        ga, gb = a[3].double(), b[3].double()
+        assert float((ga - gb).norm() / gb.norm()) < 5e-2  # (a ReLU input that is zero to rounding may flip between the modes)
+        for k in ("3Dbox", "cls", "mask"):
+            assert abs(a[4][k] - b[4][k]) <= 2e-5 * abs(b[4][k])
