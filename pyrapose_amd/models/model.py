@@ -168,7 +168,8 @@ class PyraPoseModel(object):
         with open(filepath, "rb") as f:
             magic = f.read(8)
         if magic.startswith(b"\x89HDF"):  # a real Keras / HDF5 file (whatever its name)
-            raise ImportError("load_weights: reading Keras .h5 needs h5py (not installed); convert to .npz (INTEGRATION.md)")
+            raise ImportError("load_weights: %s is a real Keras / HDF5 file and this image has no h5py; convert it where the file was made "
+                              "with `python tools/h5_to_npz.py model.h5 model.npz` (name mapping: pyrapose_amd/utils/keras_names.py)" % filepath)
         data = np.load(filepath)  # the zip container of save_weights -- also under the '.h5' names of ModelCheckpoint
         W = OrderedDict(self.get_weights_dict())
         for k in data.files:

@@ -87,12 +87,13 @@ def main():
             fh, fl = torch.zeros((taps, cout, cin), **i16), torch.zeros((taps, cout, cin), **i16)
             dh, dl = torch.zeros((taps, cin, cout), **i16), torch.zeros((taps, cin, cout), **i16)
             ops.conv_split_weights3(ctx, d, w, fh, fl, dh, dl)
-        xh, xl = torch.zeros_like(x, dtype=torch.int16), torch.zeros_like(x, dtype=torch.int16)
-        gh, gl = torch.zeros_like(dy, dtype=torch.int16), torch.zeros_like(dy, dtype=torch.int16)
+        # packed (hi, lo) planes: the storage format of the engine's default mode (ops.new_planes)
+        xh, xl = ops.new_planes(rows_in, cin)
+        gh, gl = ops.new_planes(rows, ld_w)
         ops.split_planes3(ctx, x, xh, xl)
         ops.split_planes3(ctx, dy, gh, gl)
-        yh, yl = torch.zeros((rows, ld_w), **i16), torch.zeros((rows, ld_w), **i16)
-        dxh, dxl = torch.zeros((rows_in, cin), **i16), torch.zeros((rows_in, cin), **i16)
+        yh, yl = ops.new_planes(rows, ld_w)
+        dxh, dxl = ops.new_planes(rows_in, cin)
         # a sparse gradient like the 3D-box head's: non-zero in a few square patches per image of the first level
         dys = torch.zeros_like(dy)
         h0, w0 = out_shapes[0]
@@ -103,8 +104,15 @@ def main():
                     a = (n * h0 + yy) * w0
                     dys[a + max(0, cx - r): a + min(w0, cx + r)] = dy[a + max(0, cx - r): a + min(w0, cx + r)]
         skip = ops.row_block_list(ctx, dys, cout)
-        fns = {"fwd3pp": lambda: ops.conv_fwd3(ctx, d, None, fh, fl, bias, None, True, y, x_planes=(xh, xl), y_planes=(yh, yl)),
-               "dgrad3pp": lambda: ops.conv_bwd_data3(ctx, d, None, dh, dl, None, x, dx, dy_planes=(gh, gl), dx_planes=(dxh, dxl)),
+        skip_p = ops.row_block_list(ctx, dys, cout)
+        sh, sl = ops.new_planes(rows, ld_w)
+        ops.split_planes3(ctx, dys, sh, sl)
+        fns = {"fwd3pp": lambda: ops.conv_fwd3(ctx, d, None, fh, fl, bias, None, True, None, x_planes=(xh, xl), y_planes=(yh, yl)),
+               "dgrad3pp": lambda: ops.conv_bwd_data3(ctx, d, None, dh, dl, None, None, None, dy_planes=(gh, gl), dx_planes=(dxh, dxl),
+                                                      relu_src_hi=xh),
+               "dgrad3sp": lambda: ops.conv_bwd_data3(ctx, d, None, dh, dl, None, None, None, dy_planes=(sh, sl), dx_planes=(dxh, dxl),
+                                                      relu_src_hi=xh, dy_skip=skip_p),
+               "wgrad3sp": lambda: ops.conv_bwd_weight3(ctx, d, None, None, dw, db, x_planes=(xh, xl), dy_planes=(sh, sl), dy_skip=skip_p),
                "dgrad3s": lambda: ops.conv_bwd_data3(ctx, d, dys, dh, dl, None, x, dx, dy_skip=skip),
                "wgrad3s": lambda: ops.conv_bwd_weight3(ctx, d, x, dys, dw, db, dy_skip=skip),
                "dgrad3d": lambda: ops.conv_bwd_data3(ctx, d, dys, dh, dl, None, x, dx),
