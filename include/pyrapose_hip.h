@@ -204,6 +204,21 @@ int pp_pack_rgb_to_4(pp_ctx* ctx, size_t n_pixels, const float* x3, float* x4);
  * padding and in channel 3.  sizes_hw is a HOST array of 2*n_img ints (n_img <= 64). */
 int pp_preprocess_caffe_u8(pp_ctx* ctx, int n_img, int H, int W, const int* sizes_hw_host, const unsigned char* images_u8,
                            float* x4);
+/* ---- geometric augmentation / resize of the input pipeline ------------------------------------------
+ * Replace the reference's OpenCV calls: utils/image.py:150-216 apply_transform (cv2.warpAffine of the uint8 image, INTER_LINEAR,
+ * border per TransformParameters: 'constant' / 'nearest' = replicate), :219-230 apply_transform2mask (cv2.warpAffine of the
+ * id mask, INTER_NEAREST, BORDER_CONSTANT 0), :281-323 compute_resize_scale / resize_image (cv2.resize, fx = fy = scale).
+ * OpenCV's fixed-point scheme for 8-bit images, in integer arithmetic (bit-exact against oracle/image_np.py; OpenCV itself is
+ * not installed: parity unpinned).  mats_host: n_img (<= 64) row-major 2x3 FORWARD matrices as the reference passes them to
+ * cv2.warpAffine (the kernels invert them like OpenCV does).  interpolation 0 = nearest (1 channel), 1 = linear (1 or 3
+ * channels); border 0 = constant (cval), 1 = replicate.  src / dst: [n_img][H][W][channels] uint8, distinct buffers. */
+int pp_warp_affine_u8(pp_ctx* ctx, int n_img, int H, int W, int channels, const double* mats_host, int interpolation, int border,
+                      int cval, const unsigned char* src, unsigned char* dst);
+/* compute_resize_scale (host): min side -> min_side unless the max side would exceed max_side */
+int pp_resize_scale(int rows, int cols, int min_side, int max_side, double* scale);
+/* cv2.resize(img, None, fx = fy = scale) bilinear: dst [n_img][DH][DW][channels] with DH = round(SH * scale), DW = round(SW * scale) */
+int pp_resize_linear_u8(pp_ctx* ctx, int n_img, int SH, int SW, int channels, double scale, int DH, int DW, const unsigned char* src,
+                        unsigned char* dst);
 /* The same two producers writing into a zero frame [n_img][Hp][Wp][4] with the image at (pad, pad): the input layout of
  * pp_stem7x7s2_fwd_bf16x3 (pad = 3). */
 int pp_pack_rgb_to_4_padded(pp_ctx* ctx, int n_img, int H, int W, int Hp, int Wp, int pad, const float* x3, float* x4p);

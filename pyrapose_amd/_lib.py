@@ -99,6 +99,9 @@ _SIGS = {
     "pp_upsample_nearest_add_fwd_v": (_i, [_p, _i, _i, _i, _i, _i, _i, C.POINTER(TView), C.POINTER(TView), C.POINTER(TView)]),
     "pp_upsample_nearest_add_bwd_v": (_i, [_p, _i, _i, _i, _i, _i, _i, C.POINTER(TView), C.POINTER(TView), C.POINTER(TView)]),
     "pp_merge_planes_bf16x3": (_i, [_p, _sz, _p, _p, _p]),
+    "pp_warp_affine_u8": (_i, [_p, _i, _i, _i, _i, C.POINTER(_d), _i, _i, _i, _p, _p]),
+    "pp_resize_scale": (_i, [_i, _i, _i, _i, C.POINTER(_d)]),
+    "pp_resize_linear_u8": (_i, [_p, _i, _i, _i, _i, _d, _i, _i, _p, _p]),
     "pp_conv_split_weights_bf16x3_batch": (_i, [_p, _i, _p, _i]),
     "pp_conv2d_nhwc_fwd_bf16x3": (_i, [_p, C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "pp_conv2d_nhwc_bwd_data_bf16x3": (_i, [_p, C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p]),

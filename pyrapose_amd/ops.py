@@ -277,6 +277,35 @@ def relu_fwd(ctx, x, y):
     check(lib.pp_relu_fwd(ctx.handle, x.numel(), _ptr(x), _ptr(y)), ctx.handle, "pp_relu_fwd")
 
 
+def warp_affine_u8(ctx, images_u8, matrices, interpolation="linear", border="replicate", cval=0, out=None):
+    """cv2.warpAffine per image of a uint8 batch [B,H,W,3] or [B,H,W] (utils/image.py:207-214, :222-229): matrices = B forward
+    2x3 (or 3x3) matrices on the host; interpolation 'linear' / 'nearest'; border 'replicate' ('nearest' fill mode) / 'constant'."""
+    B, H, W = images_u8.shape[:3]
+    ch = images_u8.shape[3] if images_u8.dim() == 4 else 1
+    m = np.ascontiguousarray(np.asarray(matrices, np.float64).reshape(B, -1)[:, :6])
+    if out is None:
+        out = torch.empty_like(images_u8)
+    check(lib.pp_warp_affine_u8(ctx.handle, B, H, W, ch, m.ctypes.data_as(C.POINTER(C.c_double)), {"nearest": 0, "linear": 1}[interpolation],
+                                {"constant": 0, "replicate": 1}[border], int(cval), _ptr(images_u8), _ptr(out)), ctx.handle, "pp_warp_affine_u8")
+    return out
+
+
+def resize_scale(rows, cols, min_side=480, max_side=640):
+    s = C.c_double(0)
+    check(lib.pp_resize_scale(int(rows), int(cols), int(min_side), int(max_side), C.byref(s)), None, "pp_resize_scale")
+    return s.value
+
+
+def resize_linear_u8(ctx, images_u8, scale):
+    """cv2.resize(img, None, fx=scale, fy=scale) of a uint8 batch [B,H,W,3] or [B,H,W] (utils/image.py:307-323)."""
+    B, H, W = images_u8.shape[:3]
+    ch = images_u8.shape[3] if images_u8.dim() == 4 else 1
+    dh, dw = int(np.rint(H * scale)), int(np.rint(W * scale))
+    out = torch.empty((B, dh, dw) + ((ch,) if images_u8.dim() == 4 else ()), dtype=torch.uint8, device=images_u8.device)
+    check(lib.pp_resize_linear_u8(ctx.handle, B, H, W, ch, float(scale), dh, dw, _ptr(images_u8), _ptr(out)), ctx.handle, "pp_resize_linear_u8")
+    return out
+
+
 def preprocess_caffe_u8(ctx, images_u8, sizes_hw, x4):
     """images_u8: cuda uint8 [B,H,W,3]; sizes_hw: B (h, w) pairs; x4: cuda float32 [B*H*W, 4] (the engine's stem input)."""
     Bn, H, W, _ = images_u8.shape
