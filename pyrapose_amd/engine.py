@@ -968,19 +968,27 @@ class Engine(object):
             self.grad_sync.finish()
         self.optimizer_step()
 
-    def train_step_from_annotations(self, images_u8, annotations, image_group=None):
+    def train_step_from_annotations(self, images_u8, annotations, image_group=None, transforms=None, border="replicate", cval=0):
         """The lean feed of one optimisation step: a uint8 BGR batch [B,H,W,3] (cuda, or pinned host memory) and the raw
         annotation dicts of preprocessing/generator.py:142-226 (bboxes, labels, poses, segmentations, cam_params, mask,
         mask_ids).  Mean subtraction + packing (image.py:58-60, generator.py:320-336) and target assignment
-        (utils/anchors.py:72-287) run on the device: 7.4 MB cross PCIe per batch of 8 instead of 87.9 MB."""
+        (utils/anchors.py:72-287) run on the device: 7.4 MB cross PCIe per batch of 8 instead of 87.9 MB.
+        transforms: one 2x3 / 3x3 augmentation matrix per image (utils/transform.py:random_transform): the image is warped on the
+        device like apply_transform (utils/image.py:207-214: bilinear, border = TransformParameters.fill_mode: 'replicate' for
+        the default 'nearest', or 'constant' with cval) and the id mask like apply_transform2mask; the caller has already
+        moved boxes / poses (generator.py:252-286 does that on the host: a few numbers per object)."""
         from .utils import anchors as UA
         if getattr(self, "_anchors_f64", None) is None:
             self._anchors_f64 = UA.anchors_for_shape_device((self.H, self.W), pyramid_levels=list(arch.PYRAMID_LEVELS[self.pyramid]),
                                                             anchor_params=self.anchor_params)
         xd = images_u8 if images_u8.is_cuda else images_u8.cuda(non_blocking=True)
+        if transforms is not None:
+            cur = self._enter()
+            xd = ops.warp_affine_u8(self.ctx, xd, transforms, "linear", border, cval)
+            self._leave(cur)
         if image_group is None:
             image_group = [np.empty((self.H, self.W, 3), np.uint8)] * self.B  # only the shapes are read
-        self.set_targets(*UA.anchor_targets_bbox_device(self._anchors_f64, image_group, annotations, self.C))
+        self.set_targets(*UA.anchor_targets_bbox_device(self._anchors_f64, image_group, annotations, self.C, mask_transforms=transforms))
         self.forward_u8(xd, [(int(im.shape[0]), int(im.shape[1])) for im in image_group])
         self.loss_and_backward()
         if self.grad_sync is not None:

@@ -118,8 +118,10 @@ def pack_annotations(annotations_group):
 
 
 def anchor_targets_bbox_device(anchors_dev, image_group, annotations_group, num_classes, negative_overlap=0.4,
-                               positive_overlap=0.5):
-    """Device-resident variant: anchors_dev is a cuda float64 [N,4] tensor; returns cuda float32 tensors."""
+                               positive_overlap=0.5, mask_transforms=None):
+    """Device-resident variant: anchors_dev is a cuda float64 [N,4] tensor; returns cuda float32 tensors.
+    mask_transforms: one 2x3 / 3x3 matrix per image -- the id masks are warped on the device first (apply_transform2mask,
+    utils/image.py:219-230: cv2.warpAffine INTER_NEAREST, BORDER_CONSTANT 0; all masks must then have the same size)."""
     assert len(image_group) == len(annotations_group), "The length of the images and annotations need to be equal."
     assert len(annotations_group) > 0, "No data received to compute anchor targets for."
     ctx = default_context()
@@ -136,6 +138,9 @@ def anchor_targets_bbox_device(anchors_dev, image_group, annotations_group, num_
         for i, m in enumerate(ms):
             plane[i, : m.shape[0], : m.shape[1]] = m
         masks = torch.from_numpy(plane).cuda()
+        if mask_transforms is not None:
+            assert all(hw == mask_hw[0] for hw in mask_hw), "device mask augmentation needs equally sized masks"
+            masks = ops.warp_affine_u8(ctx, masks, mask_transforms, "nearest", "constant", 0)
     return ops.anchor_targets(ctx, anchors_dev, offs, dev(boxes), dev(labels), dev(box3d), dev(mids), masks, mask_hw, image_hw,
                               num_classes, mh, mw, negative_overlap, positive_overlap)
 

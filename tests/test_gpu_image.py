@@ -91,3 +91,40 @@ def test_resize_bit_exact_vs_oracle(ctx):
     assert ops.resize_scale(400, 1200) == IM.compute_resize_scale((400, 1200, 3))
     g1 = ops.resize_linear_u8(ctx, torch.from_numpy(img[:, :, :, 0].copy()).cuda(), 0.5).cpu().numpy()
     assert np.array_equal(g1[1], IM.resize_linear_u8(img[1, :, :, 0], 0.5))
+
+
+def test_lean_feed_with_device_augmentation(ctx):
+    """Engine.train_step_from_annotations(transforms=...): identity transforms change nothing; a real transform gives the
+    step that the same feed takes on the host-warped image and mask (oracle warp) -- losses equal."""
+    import bench
+    from oracle import image_np as IM
+    from pyrapose_amd import arch
+    from pyrapose_amd.engine import Engine
+    B, H, W, C = 2, 96, 128, 5
+    rng = np.random.default_rng(5)
+    _, images, anns = bench.synth_batch(B, H, W, C, seed=3, side=(20, 50))
+    u8 = rng.integers(0, 256, (B, H, W, 3)).astype(np.uint8)
+    Wt = arch.init_weights(C, seed=4)
+    ident = [np.eye(3) for _ in range(B)]
+    mats = [random_transform(rng, H, W) for _ in range(B)]
+
+    def step(img, ann, tf):
+        eng = Engine(ctx, C, B, H, W, weights=Wt, train=True)
+        eng.train_step_from_annotations(torch.from_numpy(img).cuda(), ann, transforms=tf)
+        torch.cuda.synchronize()
+        out = eng.losses()
+        eng.close()
+        return out
+    base = step(u8, anns, None)
+    same = step(u8, anns, ident)
+    assert all(abs(base[k] - same[k]) <= 1e-6 * max(abs(base[k]), 1e-6) for k in base)
+    dev = step(u8, anns, mats)
+    warped = np.stack([IM.warp_affine_u8(u8[b], mats[b], "linear", "replicate") for b in range(B)])
+    anns_w = []
+    for b, a in enumerate(anns):
+        a2 = dict(a)
+        a2["mask"] = [IM.warp_affine_u8(np.asarray(a["mask"][0], np.uint8), mats[b], "nearest", "constant", 0)]
+        anns_w.append(a2)
+    host = step(warped, anns_w, None)
+    assert all(abs(dev[k] - host[k]) <= 1e-6 * max(abs(host[k]), 1e-6) for k in host), (dev, host)
+    assert abs(dev["total"] - base["total"]) > 1e-4   # (the transform did change the step)

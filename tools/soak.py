@@ -18,6 +18,8 @@ from pyrapose_amd.runtime import default_context  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=120)
 ap.add_argument("--lr", type=float, default=1e-4)
+ap.add_argument("--augment", action="store_true", help="a fresh random affine transform per image and step, applied on the device "
+                "(image: bilinear warp, id mask: nearest warp) -- SURVEY 8f3")
 args = ap.parse_args()
 B, H, W, C = 8, 480, 640, 13
 eng = Engine(default_context(), C, B, H, W, weights=arch.init_weights(C, seed=0), train=True, lr=args.lr)
@@ -31,7 +33,14 @@ torch.cuda.synchronize()
 t0 = time.perf_counter()
 for s in range(args.steps):
     u8, anns = batches[s % len(batches)]
-    eng.train_step_from_annotations(u8, anns)
+    tf = None
+    if args.augment:  # utils/transform.py: scaling 0.9 .. 1.1, translation +-10 % about the image centre (bin/train.py:189-199)
+        tf = []
+        for _ in range(B):
+            sc, t = rng.uniform(0.9, 1.1), rng.uniform(-0.1, 0.1, 2) * np.array([W, H])
+            c = np.array([0.5 * W, 0.5 * H])
+            tf.append(np.array([[sc, 0, c[0] - sc * c[0] + t[0]], [0, sc, c[1] - sc * c[1] + t[1]], [0, 0, 1.0]]))
+    eng.train_step_from_annotations(u8, anns, transforms=tf)
     if s % 10 == 0 or s + 1 == args.steps:
         l = eng.losses()
         assert all(np.isfinite(v) for v in l.values()), (s, l)
