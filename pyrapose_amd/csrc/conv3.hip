@@ -1969,7 +1969,8 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
                                                                             const void* __restrict__ g_x1, unsigned x_bytes,
                                                                             const void* __restrict__ g_d0, const void* __restrict__ g_d1,
                                                                             unsigned d_bytes, float* __restrict__ g_dw,
-                                                                            float* __restrict__ g_dbias, const int* __restrict__ g_list) {
+                                                                            float* __restrict__ g_dbias, const int* __restrict__ g_list,
+                                                                            float* __restrict__ g_ws, long long ws_slice) {
   constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32;
   constexpr int PA = BM + 32, PB = BN + 32;  // LDS pitches in bf16 elements (row + 64 bytes)
   constexpr int ES = 4;              // f32, or packed planes (32-byte groups of 8 channels: hi, then lo = the *1 resources)
@@ -2212,16 +2213,25 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
   if (do_bias) k_loop(std::true_type{});
   else k_loop(std::false_type{});
 
+  // Reduction over the row splits.  With a scratch buffer (pp_ctx_set_workspace): split s writes its partial tile -- plain
+  // stores, every column of the tile below ld_w, zeros past Cout -- into slice s, a full-size copy of dW (+ one bias row), and
+  // wgrad_finish_kernel adds the slices in a fixed order: deterministic, and the partial sums leave the chip at store speed
+  // instead of the ~1.3 TB/s of float atomics (MI355X_MICROARCH.md: they execute at the memory side).  Without it: atomics.
+  float* const slice = g_ws ? g_ws + (long long)split * ws_slice : nullptr;
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ci = ci0 + wm * 32 * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      float* dst = g_dw + (long long)(tap * p.Cin + ci) * p.ld_w;
+      const long long row = (long long)(tap * p.Cin + ci) * p.ld_w;
 #pragma unroll
       for (int c = 0; c < TN; ++c) {
         const int co = n0 + wn * 32 * TN + c * 32 + il;
-        if (co < p.Cout) atomicAdd(dst + co, acc[a][c][r]);
+        if (slice) {
+          if (co < p.ld_w) slice[row + co] = co < p.Cout ? acc[a][c][r] : 0.f;
+        } else if (co < p.Cout) {
+          atomicAdd(g_dw + row + co, acc[a][c][r]);
+        }
       }
     }
   }
@@ -2244,8 +2254,31 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
       float s = 0.f;
 #pragma unroll 8
       for (int r = 0; r < 32; ++r) s += red[r * BN + tid];
-      if (n0 + tid < p.Cout) atomicAdd(g_dbias + n0 + tid, s);
+      if (slice) {
+        if (n0 + tid < p.ld_w) slice[ws_slice - p.ld_w + n0 + tid] = n0 + tid < p.Cout ? s : 0.f;  // the bias row closes the slice
+      } else if (n0 + tid < p.Cout) {
+        atomicAdd(g_dbias + n0 + tid, s);
+      }
     }
+  }
+}
+
+// dw += sum_s slice_s (fixed order), dbias += the slices' last row; n4 = float4 groups of one slice (dW + the bias row)
+__global__ void wgrad_finish_kernel(long long n4_dw, int ld4, int splits, long long ws_slice4, const float4* __restrict__ ws, float4* __restrict__ dw,
+                                    float4* __restrict__ dbias) {
+  const long long total = n4_dw + (dbias ? ld4 : 0);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const bool is_bias = i >= n4_dw;
+    const long long src = is_bias ? ws_slice4 - ld4 + (i - n4_dw) : i;
+    float4 v = ws[src];
+    for (int s = 1; s < splits; ++s) {
+      const float4 q = ws[src + s * ws_slice4];
+      v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    float4* dst = is_bias ? dbias + (i - n4_dw) : dw + i;
+    float4 o = *dst;
+    o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+    *dst = o;
   }
 }
 
@@ -2272,9 +2305,20 @@ static void launch_wgrad3(pp_ctx* ctx, Wgrad3Params& p, const float* x, const fl
   const bool fast = fast_on && x_bytes < (1ll << 31) && d_bytes < (1ll << 31) && p.M < (1 << 24) && p.src_rows > 0 && min_hw >= 32;
   const int slots = fast ? ((TM * TN == 4) ? 3 : 4) : ((TM * TN == 4) ? 2 : 3);
   const double tile_work = (double)(TM * TN) / 4.0;
-  // f32 atomics of one split's tiles at ~1.3 TB/s, half of it hidden under the k-loops of other workgroups (measured:
-  // 256-channel head convs 252 -> 234 us going from 14 to 21 splits, i.e. from 2 to 3 workgroups per CU)
-  const double atomic_us_per_split = 0.5 * (double)tiles * BM * BN * 4.0 / 1.3e6;
+  // one slice = a full-size copy of dW plus a bias row (f32).  PP_WGRAD3_DETERMINISTIC=1 (and a scratch buffer): the splits write
+  // slices and a finishing pass adds them in a fixed order -- bit-reproducible gradients; default: float atomics into dW, which
+  // are fire-and-forget and overlap the k-loops of other workgroups (measured in the training step, same box, slices vs
+  // atomics: 531.5 vs 537.1 images/s, dense backward 424 vs 433: the extra pass and its launch cost more than the atomics)
+  const long long ws_slice = (long long)p.kh * p.kw * p.Cin * p.ld_w + p.ld_w;
+  const bool use_ws = fast && ctx->ws != nullptr && (long long)ctx->ws_bytes >= ws_slice * 4 && ((uintptr_t)dw & 15u) == 0 &&
+                      (!dbias || ((uintptr_t)dbias & 15u) == 0) && []() { const char* e = getenv("PP_WGRAD3_DETERMINISTIC"); return e && e[0] == '1'; }();
+  if (use_ws) {
+    const long long fit = (long long)ctx->ws_bytes / (ws_slice * 4);
+    if (max_splits > fit) max_splits = (int)fit;
+  }
+  // per split: atomics = |dW| at ~1.3 TB/s, half of it hidden under the k-loops of other workgroups (measured: 256-channel
+  // head convs 252 -> 234 us going from 14 to 21 splits); slices = |dW| written and read back once at ~4 TB/s
+  const double atomic_us_per_split = use_ws ? (double)tiles * BM * BN * 4.0 * 2.0 / 4.0e6 : 0.5 * (double)tiles * BM * BN * 4.0 / 1.3e6;
   int splits = 1;
   double best = 1e300;
   for (int sp = 1; sp <= max_splits; ++sp) {
@@ -2295,19 +2339,27 @@ static void launch_wgrad3(pp_ctx* ctx, Wgrad3Params& p, const float* x, const fl
   splits = (p.M + rps - 1) / rps;
   p.splits = splits;
   p.rows_per_split = rps;
+  float* const ws = (use_ws && splits > 1) ? ctx->ws : nullptr;  // (a single split adds its tile straight into dW)
   if (fast) {
     if (xhi && list)
       hipLaunchKernelGGL((wgrad3f_kernel<TM, TN, true, true>), dim3((unsigned)(tiles * splits)), dim3(256), 0, ctx->stream, p, xhi, xlo,
-                         (unsigned)x_bytes, dhi, dlo, (unsigned)d_bytes, dw, dbias, list);
+                         (unsigned)x_bytes, dhi, dlo, (unsigned)d_bytes, dw, dbias, list, ws, ws_slice);
     else if (xhi)
       hipLaunchKernelGGL((wgrad3f_kernel<TM, TN, true, false>), dim3((unsigned)(tiles * splits)), dim3(256), 0, ctx->stream, p, xhi, xlo,
-                         (unsigned)x_bytes, dhi, dlo, (unsigned)d_bytes, dw, dbias, (const int*)nullptr);
+                         (unsigned)x_bytes, dhi, dlo, (unsigned)d_bytes, dw, dbias, (const int*)nullptr, ws, ws_slice);
     else if (list)
       hipLaunchKernelGGL((wgrad3f_kernel<TM, TN, false, true>), dim3((unsigned)(tiles * splits)), dim3(256), 0, ctx->stream, p, (const void*)x,
-                         nullptr, (unsigned)x_bytes, (const void*)dy, nullptr, (unsigned)d_bytes, dw, dbias, list);
+                         nullptr, (unsigned)x_bytes, (const void*)dy, nullptr, (unsigned)d_bytes, dw, dbias, list, ws, ws_slice);
     else
       hipLaunchKernelGGL((wgrad3f_kernel<TM, TN, false, false>), dim3((unsigned)(tiles * splits)), dim3(256), 0, ctx->stream, p, (const void*)x,
-                         nullptr, (unsigned)x_bytes, (const void*)dy, nullptr, (unsigned)d_bytes, dw, dbias, (const int*)nullptr);
+                         nullptr, (unsigned)x_bytes, (const void*)dy, nullptr, (unsigned)d_bytes, dw, dbias, (const int*)nullptr, ws, ws_slice);
+    if (ws) {
+      const long long n4 = (ws_slice - p.ld_w) / 4;
+      long long blocks = (n4 + p.ld_w / 4 + 255) / 256;
+      if (blocks > (long long)cus * 8) blocks = (long long)cus * 8;
+      hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, n4, p.ld_w / 4, splits, ws_slice / 4,
+                         (const float4*)ws, (float4*)dw, (float4*)dbias);
+    }
   } else if (xhi)
     hipLaunchKernelGGL((wgrad3_kernel<TM, TN, true>), dim3((unsigned)(tiles * splits)), dim3(256), 0, ctx->stream, p, x, dy, (const uint4*)xhi,
                        (const uint4*)xlo, (const uint4*)dhi, (const uint4*)dlo, dw, dbias);

@@ -286,7 +286,8 @@ class Engine(object):
         self.ctxs = [ctx] + [ops.Context(ctx.device, st) for st in self.streams[1:]]
         # split-K scratch (one per lane): the small-M convs of res5 / FPN level 5 cannot fill 256 CUs with output tiles
         # alone (3x3 512->512 on 2400 rows: 112 -> 174 TFLOP/s with 4 slices).  Deterministic (fixed-order slice sum).
-        ws_mb = int(os.environ.get("PP_SPLITK_MB", "64"))
+        # (also the slices of the weight-gradient launches: splits x |dW| in f32, e.g. 16 x 9.4 MB for the 512-wide head convs)
+        ws_mb = int(os.environ.get("PP_SPLITK_MB", "256"))
         if self.conv_mode == "bf16x3" and ws_mb > 0:
             for c in self.ctxs:
                 c.set_workspace(ws_mb << 20)
@@ -513,7 +514,9 @@ class Engine(object):
         self.reg_out = run_head("reg", pyr)
         self._lane = 1 % self.n_lanes
         self.cls_out = run_head("cls", pyr)
-        self._lane = 2 % self.n_lanes
+        # the mask head (P3 only: 0.6 ms) follows the class head on lane 1 when there are two lanes: the 3D-box head (2.3 ms)
+        # has lane 0 to itself and both lanes stay busy for longer (PP_MASK_LANE overrides)
+        self._lane = int(_os.environ.get("PP_MASK_LANE", "1" if self.n_lanes == 2 else "2")) % self.n_lanes
         self.mask_out = run_head("mask", P3)
         self._lane = 0
         # interleave the three chains in enqueue order so that every lane has work from the start

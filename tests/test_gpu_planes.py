@@ -288,3 +288,46 @@ def test_engine_planes_mode_matches_f32_storage(ctx, mode, monkeypatch):
         assert float((ga - gb).norm() / gb.norm()) < 5e-2  # (a ReLU input that is zero to rounding may flip between the modes)
         for k in ("3Dbox", "cls", "mask"):
             assert abs(a[4][k] - b[4][k]) <= 2e-5 * abs(b[4][k])
+
+
+@pytest.mark.parametrize("case", [c for c in WG3_CASES if c[0] in ("head3x3_multilevel", "head_out_cout117", "lat1x1", "down3x3s2_odd", "x_five_levels")],
+                         ids=lambda c: c[0])
+def test_weight_gradient_slices_are_deterministic_and_match_atomics(ctx, case, monkeypatch):
+    """PP_WGRAD3_DETERMINISTIC=1 + a scratch buffer: the row splits of the weight gradient write slices that a finishing pass
+    adds in a fixed order (no float atomics): bit-identical from run to run, equal to the atomic path up to summation order,
+    dw += semantics kept.  (Off by default: 1-2 % slower in the training step.)"""
+    from pyrapose_amd import ops
+    d, wd, ld_w, ld_y, cred, xs, bias, out_shapes, B, cin, cout = _geometry(case)
+    rng = np.random.default_rng(4)
+    x = _cat_rows(xs)
+    rows_out = sum(B * h * w for h, w in out_shapes)
+    gy = torch.zeros((rows_out, ld_y), dtype=torch.float32, device="cuda")
+    gy[:, :cout] = torch.as_tensor(rng.standard_normal((rows_out, cout)), dtype=torch.float32).cuda()
+    xp, gp = split(ctx, x), split(ctx, gy)
+    base = torch.as_tensor(rng.standard_normal(tuple(wd.shape)), dtype=torch.float32).cuda()  # dw += : start from something
+
+    def run(planes):
+        dw, db = base.clone(), torch.ones((ld_w,), dtype=torch.float32, device="cuda")
+        if planes:
+            ops.conv_bwd_weight3(ctx, d, None, None, dw, db, x_planes=xp, dy_planes=gp)
+        else:
+            ops.conv_bwd_weight3(ctx, d, x, gy, dw, db)
+        torch.cuda.synchronize()
+        return dw, db
+    monkeypatch.setenv("PP_WGRAD3_SPLITS", "3")
+    monkeypatch.setenv("PP_WGRAD3_DETERMINISTIC", "1")
+    a_dw, a_db = run(True)                       # no scratch buffer: atomics
+    ctx.set_workspace(64 << 20)
+    try:
+        ctx.workspace.fill_(float("nan"))        # any contents: every word the finishing pass reads was written by the launch
+        s_dw, s_db = run(True)
+        s_dw2, s_db2 = run(True)
+        f_dw, f_db = run(False)                  # float32 operands, same reduction
+    finally:
+        ctx.set_workspace(0)
+    assert torch.equal(s_dw, s_dw2) and torch.equal(s_db, s_db2)
+    scale = float((a_dw - base).abs().max())
+    assert float((s_dw - a_dw).abs().max()) <= 2e-6 * scale and float((f_dw - a_dw).abs().max()) <= 2e-6 * scale
+    assert float((s_db - a_db).abs().max()) <= 2e-5 * max(float((a_db - 1).abs().max()), 1e-30)
+    assert bool(s_dw.isfinite().all()) and float((s_dw - base).abs().max()) > 0
+    assert torch.equal(s_dw[:, cout:], base[:, cout:])   # padding columns: + 0
