@@ -472,7 +472,7 @@ def main_worker(args):
     roofline = None
     if roof and "achieved" in roof:
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tpath) and (C, H, W, B) == (13, 480, 640, 8):
             with open(tpath) as f:
                 tj = json.load(f)
