@@ -266,6 +266,8 @@ def parse_args(argv=None):
     ap.add_argument("--classes", type=int, default=13)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--backbone", default="resnet50", choices=["resnet50", "resnet101"],
+                    help="resnet101 = the [3,4,23,3] variant of BASELINE configs[4] (with --height 540 --width 720 --classes 30)")
     ap.add_argument("--conv-mode", default=None, choices=["f32", "bf16x3"], help="default: env PP_CONV_MODE or bf16x3")
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the short run of the other conv mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -323,13 +325,13 @@ def main_worker(args):
 
     B, H, W, C = args.batch, args.height, args.width, args.classes
     ctx = default_context(local_rank)
-    weights = arch.init_weights(C, seed=0)
+    weights = arch.init_weights(C, seed=0, backbone=args.backbone)
     x, images, anns = synth_batch(B, H, W, C, seed=1000 + rank)
     anchors = UA.anchors_for_shape_device((H, W))
     y_box, y_cls, y_mask = UA.anchor_targets_bbox_device(anchors, images, anns, C)
     x_dev = torch.from_numpy(x).cuda()
-    fwd_fl, bwd_fl = arch.conv_flops(C, H, W)
-    algo_gflop = ALGO_GFLOP_PER_IMAGE.get((C, H, W), (fwd_fl + bwd_fl) / 1e9)
+    fwd_fl, bwd_fl = arch.conv_flops(C, H, W, args.backbone)
+    algo_gflop = ALGO_GFLOP_PER_IMAGE.get((C, H, W), (fwd_fl + bwd_fl) / 1e9) if args.backbone == "resnet50" else (fwd_fl + bwd_fl) / 1e9
 
     def barrier():
         torch.cuda.synchronize()
@@ -355,7 +357,7 @@ def main_worker(args):
         """Build an engine in `mode`, run warmup + timed steps, return (dt, images, losses, roofline dict)."""
         if sparse is not None:
             os.environ["PP_SPARSE_BWD"] = sparse
-        eng = Engine(ctx, C, B, H, W, weights=weights, train=True, conv_mode=mode)
+        eng = Engine(ctx, C, B, H, W, backbone=args.backbone, weights=weights, train=True, conv_mode=mode)
         os.environ.pop("PP_SPARSE_BWD", None) if sparse is not None else None
         if world > 1:
             DataParallel(eng)
@@ -537,8 +539,12 @@ def main_worker(args):
         "dtype_note": ("every conv product = x_hi*w_hi + x_hi*w_lo + x_lo*w_hi on bf16 MFMA with f32 accumulation (2^-16 relative); "
                        "activations, master weights, losses and Adam in float32; head outputs within 1e-3 of the float64 oracle "
                        "(tests/test_gpu_model.py)") if mode == "bf16x3" else "exact f32 MFMA (v_mfma_f32_32x32x2_f32) everywhere",
-        "config": {"workload": "LineMOD %d-class training, batch %d/GPU, %dx%d, ResNet-50 PFPN + heads (BASELINE configs[1])"
-                               % (C, B, W, H), "global_batch": B * world, "parallelism": "dp%d" % world,
+        "config": {"workload": "%s %d-class training, batch %d/GPU, %dx%d, %s PFPN + heads (BASELINE configs[%s])"
+                               % ("LineMOD" if C == 13 else ("YCB-Video" if C == 21 else ("T-LESS" if C == 30 else "synthetic")), C, B, W, H,
+                                  {"resnet50": "ResNet-50", "resnet101": "ResNet-101"}[args.backbone],
+                                  "1" if (C, H, W, args.backbone) == (13, 480, 640, "resnet50") else
+                                  ("3" if (C, H, W, args.backbone) == (21, 480, 640, "resnet50") else
+                                   ("4" if (C, H, W, args.backbone) == (30, 540, 720, "resnet101") else "-"))), "global_batch": B * world, "parallelism": "dp%d" % world,
                    "algorithmic_gflop_per_image": algo_gflop},
         "step_tflops": images_total * algo_gflop / dt / 1e3,
         "losses": losses,
