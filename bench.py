@@ -434,13 +434,22 @@ def main_worker(args):
                 else:
                     cur_e = max(cur_e, t_e)
             union += cur_e - cur_s
+            # the largest single launch (most algorithmic flops), by its own event-bracketed interval (launches of the other lane
+            # overlap it, so this is a lower bound on the kernel's stand-alone rate; profiles/ holds the rocprofv3 durations)
+            big = {}
+            for kind, name, flops, s_ev, e_ev in records:
+                b = big.setdefault((kind, name), [flops, 0.0, 0])
+                b[1] += s_ev.elapsed_time(e_ev) * 1e-3
+                b[2] += 1
+            (bk, bn), (bfl, bsec, bcnt) = max(((k, v) for k, v in big.items() if k[0] == "conv_fwd"), key=lambda kv: kv[1][0])
+            largest = {"launch": "%s %s" % (bk, bn), "gflop": bfl / 1e9, "avg_us": 1e6 * bsec / bcnt, "tflops": bfl / (bsec / bcnt) / 1e12}
             names = {"conv_fwd": "igemm fwd", "conv_dgrad": "igemm bwd-data", "conv_wgrad": "wgrad"}
             kernels = [{"kernel": names[k], "launches": n, "avg_ms": 1e3 * sec / n, "tflops_own_interval": fl / sec / 1e12}
                        for k, (fl, sec, n) in agg.items()]
             fl = sum(v[0] for v in agg.values())
             roof = {"achieved": dense_flops / union / 1e12, "executed": fl / union / 1e12, "sparse": sp_frac,
                     "conv_share_of_step": union / (dt * n_sampled / steps), "lanes": eng.n_lanes,
-                    "sampled_steps": n_sampled,
+                    "sampled_steps": n_sampled, "largest_launch": largest,
                     "dominant": max(agg.items(), key=lambda kv: kv[1][1])[0], "per_kernel": kernels}
             if dump_ops:
                 per, order = {}, []
@@ -499,6 +508,8 @@ def main_worker(args):
                     "vs_f32_mfma_peak_157.3": roof["executed"] / PEAK_F32_MFMA_TFLOPS,
                     "measured_peak": measured_peak(mode, roof["executed"]),
                     "dominant": roof["dominant"], "conv_share_of_step": roof["conv_share_of_step"], "lanes": roof["lanes"],
+                    "largest_launch": dict(roof["largest_launch"], frac=roof["largest_launch"]["tflops"] / peak,
+                                           mfma_issue_frac=roof["largest_launch"]["tflops"] * mm / peak),
                     "per_kernel": roof["per_kernel"]}
 
     other = None
