@@ -1687,6 +1687,7 @@ struct Wgrad3Params {
   int kh, kw, stride, pad_t, pad_l;
   int k_tiles_per_tap, n_tiles_k, n_tiles_n, splits, rows_per_split;
   int max_wraps;  // ceil(32 / narrowest level width): row wraps one 32-row step can cross
+  int sp_min_steps;  // SP: listed 32-row blocks one workgroup should at least reduce (fewer splits when the list is short)
   long long src_rows;
 };
 
@@ -1998,9 +1999,17 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
   int s_idx = 0, s_end = 0;
   const int blk_past = (p.M + BK - 1) / BK;  // SP: "no more blocks" (its rows are >= M: loads return zeros)
   if (SP) {
+    // The grid was sized on the host for the dense reduction; a short list is shared by FEWER splits (uniform early exit of
+    // the others, before any barrier): every split adds a full |dW| tile set with float atomics, which at 12 blocks per
+    // split cost more than the reduction itself (3D-box head on the bench targets: 16 splits x 9.4 MB of atomics for ~200
+    // listed blocks).  The slices of the deterministic mode need every split's slice written: no reduction there.
     const int n_act = g_list[0];
-    s_idx = (int)((long long)n_act * split / p.splits);
-    s_end = (int)((long long)n_act * (split + 1) / p.splits);
+    int s_eff = (n_act + p.sp_min_steps - 1) / p.sp_min_steps;
+    s_eff = s_eff < 1 ? 1 : (s_eff > p.splits ? p.splits : s_eff);
+    if (g_ws) s_eff = p.splits;
+    if (split >= s_eff) return;
+    s_idx = (int)((long long)n_act * split / s_eff);
+    s_end = (int)((long long)n_act * (split + 1) / s_eff);
     n_steps = s_end - s_idx;
     m_begin = (n_steps > 0 ? g_list[1 + s_idx] : blk_past) * BK;
     m_end = p.M;
@@ -2050,6 +2059,8 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
   };
   decode(m_cur);
   const int n_wraps = p.max_wraps;
+  int q_next = blk_past;  // SP: the listed block of the step after the one being loaded
+  if (SP) q_next = (s_idx + 1 < s_end) ? g_list[1 + s_idx + 1] : blk_past;
 
   auto load_step = [&]() {
     const int m = m_cur;
@@ -2073,9 +2084,11 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
     }
   };
   auto next_row = [&]() {  // m_cur += 32
-    if (SP) {  // jump to the next listed block: full decode (two reciprocal divisions per step)
+    if (SP) {  // jump to the next listed block: full decode (two reciprocal divisions per step).  The list entry was fetched one
+               // step ahead (q_next): a dependent global load in front of the operand loads cost ~1 us per step
       ++s_idx;
-      m_cur = (s_idx < s_end ? g_list[1 + s_idx] : blk_past) * BK + prow;
+      m_cur = q_next * BK + prow;
+      q_next = (s_idx + 1 < s_end) ? g_list[1 + s_idx + 1] : blk_past;
       decode(m_cur);
       return;
     }
@@ -2339,6 +2352,10 @@ static void launch_wgrad3(pp_ctx* ctx, Wgrad3Params& p, const float* x, const fl
   splits = (p.M + rps - 1) / rps;
   p.splits = splits;
   p.rows_per_split = rps;
+  {
+    static const int sp_steps = []() { const char* e = getenv("PP_WGRAD3_SP_STEPS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1; }();
+    p.sp_min_steps = sp_steps;
+  }
   float* const ws = (use_ws && splits > 1) ? ctx->ws : nullptr;  // (a single split adds its tile straight into dW)
   if (fast) {
     if (xhi && list)
