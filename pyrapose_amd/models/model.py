@@ -9,6 +9,7 @@ over) when the batch shape changes.
 """
 import os
 from collections import OrderedDict
+from struct import error as struct_error
 
 import numpy as np
 import torch
@@ -168,9 +169,25 @@ class PyraPoseModel(object):
         with open(filepath, "rb") as f:
             magic = f.read(8)
         if magic.startswith(b"\x89HDF"):  # a real Keras / HDF5 file (whatever its name)
-            raise ImportError("load_weights: %s is a real Keras / HDF5 file and this image has no h5py; convert it where the file was made "
-                              "with `python tools/h5_to_npz.py model.h5 model.npz` (name mapping: pyrapose_amd/utils/keras_names.py)" % filepath)
-        data = np.load(filepath)  # the zip container of save_weights -- also under the '.h5' names of ModelCheckpoint
+            # no h5py / libhdf5 in this image: the subset reader of utils/hdf5_lite.py (version-0 superblock, old-style groups,
+            # contiguous datasets -- what Keras 2.3.1 writes) + the Keras -> tensor name mapping.  Written to the HDF5
+            # specification, not verified against libhdf5 output: tools/h5_to_npz.py (h5py) is the reference route.
+            from ..utils import hdf5_lite, keras_names
+            try:
+                layers = hdf5_lite.read_keras_weights(filepath)
+                data_dict = keras_names.keras_to_tensors(layers, partial=bool(by_name))
+            except (hdf5_lite.H5Unsupported, ValueError, KeyError, IndexError, struct_error) as e:
+                raise ImportError("load_weights: %s is an HDF5 file that the built-in subset reader cannot take (%s: %s); convert it "
+                                  "where it was made with `python tools/h5_to_npz.py model.h5 model.npz`" % (filepath, type(e).__name__, e))
+
+            class _D(object):
+                files = list(data_dict)
+
+                def __getitem__(self_, k):
+                    return data_dict[k]
+            data = _D()
+        else:
+            data = np.load(filepath)  # the zip container of save_weights -- also under the '.h5' names of ModelCheckpoint
         W = OrderedDict(self.get_weights_dict())
         for k in data.files:
             if k not in W:
@@ -189,8 +206,15 @@ class PyraPoseModel(object):
             self._engine.refresh_planes()
             self._engine._weights_version = self._weights_version
 
-    def save_weights(self, filepath):
-        """numpy container, written under exactly the given name (the reference's snapshot names end in '.h5')."""
+    def save_weights(self, filepath, format=None):
+        """format None / 'npz': numpy container, written under exactly the given name (the reference's snapshot names end in
+        '.h5'; load_weights recognises the container by content).  format 'h5': an HDF5 file in Keras-2.3.1's save_weights
+        layout (utils/hdf5_lite.py writer + the name mapping of utils/keras_names.py) -- what the reference's own
+        `load_weights(by_name=True)` would read; unverified against libhdf5 (none in this image)."""
+        if format == "h5":
+            from ..utils import hdf5_lite, keras_names
+            hdf5_lite.write_keras_weights(filepath, keras_names.tensors_to_keras(self.get_weights_dict()))
+            return
         with open(filepath, "wb") as f:
             np.savez(f, **self.get_weights_dict())
 

@@ -27,11 +27,13 @@ def _strip(name):
     return name[:-2] if name.endswith(":0") else name
 
 
-def keras_to_tensors(layers, expected_shapes=None):
+def keras_to_tensors(layers, expected_shapes=None, partial=False):
     """layers: {layer_group_name: {weight_name: array}} as read from a Keras .h5 ('model_weights' group or file root;
     weight names like 'res2a_branch2a/kernel:0', 'bn2a_branch2a/moving_mean:0', 'conv2d_7/bias:0').
     Returns {'<layer>/kernel' (HWIO), '<layer>/bias', '<bn>/{gamma,beta,mean,var}'} with this package's layer names.
-    expected_shapes: optional {name: shape} (e.g. from arch.init_weights) checked against the result."""
+    expected_shapes: optional {name: shape} (e.g. from arch.init_weights) checked against the result.
+    partial: the file holds only part of the graph (the ImageNet backbone of models/resnet.py:89-98, loaded by_name): map the
+    explicitly named layers, deal out the auto-named convs only when all of them are there, check shapes of what was found."""
     flat = OrderedDict()
     for group, ws in layers.items():
         for wname, arr in ws.items():
@@ -50,7 +52,9 @@ def keras_to_tensors(layers, expected_shapes=None):
         else:
             raise ValueError("unexpected Keras weight %r" % full)
     ks = sorted(auto)
-    if len(ks) != len(AUTO_ORDER):
+    if partial and len(ks) != len(AUTO_ORDER):
+        ks = []
+    elif len(ks) != len(AUTO_ORDER):
         raise ValueError("expected %d auto-named Conv2D layers (heads + FPN), found %d: %s" % (len(AUTO_ORDER), len(ks), ks))
     for k, ours in zip(ks, AUTO_ORDER):
         for var, arr in auto[k].items():
@@ -58,6 +62,8 @@ def keras_to_tensors(layers, expected_shapes=None):
     if expected_shapes is not None:
         for name, shape in expected_shapes.items():
             if name not in out:
+                if partial:
+                    continue
                 raise ValueError("Keras file has no tensor for %s" % name)
             if tuple(out[name].shape) != tuple(shape):
                 raise ValueError("shape of %s: Keras %s, expected %s" % (name, out[name].shape, tuple(shape)))

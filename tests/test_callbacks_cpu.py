@@ -43,13 +43,37 @@ def test_checkpoint_save_best_only_and_period(tmp_path):
     assert sorted(f for f in os.listdir(str(tmp_path)) if f.startswith("e")) == ["e02.h5", "e04.h5"]
 
 
-def test_real_hdf5_is_refused_by_content_not_by_name(tmp_path):
+def test_hdf5_is_recognised_by_content_not_by_name(tmp_path):
+    """a file that starts with the HDF5 signature goes to the subset reader whatever it is called: a broken one is refused
+    with the conversion command, a Keras-layout one (here from our own writer) loads"""
+    import numpy as np
     model = models.backbone("resnet50").retinanet(num_classes=2)
     p = os.path.join(str(tmp_path), "keras.h5")
     with open(p, "wb") as f:
         f.write(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
-    with pytest.raises(ImportError):
+    with pytest.raises(ImportError) as e:
         model.load_weights(p)
+    assert "h5_to_npz" in str(e.value)
+    good = os.path.join(str(tmp_path), "snapshot.weights")
+    model.save_weights(good, format="h5")
+    with open(good, "rb") as f:
+        assert f.read(4) == b"\x89HDF"
+    m2 = models.backbone("resnet50").retinanet(num_classes=2)
+    m2._weights = {k: np.zeros_like(v) for k, v in m2.get_weights_dict().items()}
+    m2.load_weights(good)
+    a, b = model.get_weights_dict(), m2.get_weights_dict()
+    assert sorted(a) == sorted(b) and all(np.array_equal(a[k], b[k]) for k in a)
+    # by_name on a backbone-only file (the ImageNet weights of models/resnet.py:89-98): named layers load, heads stay
+    from pyrapose_amd.utils import hdf5_lite, keras_names
+    layers = keras_names.tensors_to_keras(a)
+    part = {g: w for g, w in layers.items() if g.startswith(("conv1", "bn", "res"))}
+    hdf5_lite.write_keras_weights(os.path.join(str(tmp_path), "imagenet.h5"), part)
+    m3 = models.backbone("resnet50").retinanet(num_classes=2)
+    before = m3.get_weights_dict()["reg_out/kernel"].copy()
+    m3._weights = dict(m3.get_weights_dict(), **{"res3a_branch2a/kernel": np.zeros_like(a["res3a_branch2a/kernel"])})
+    m3.load_weights(os.path.join(str(tmp_path), "imagenet.h5"), by_name=True, skip_mismatch=True)
+    c = m3.get_weights_dict()
+    assert np.array_equal(c["res3a_branch2a/kernel"], a["res3a_branch2a/kernel"]) and np.array_equal(c["reg_out/kernel"], before)
 
 
 def test_reduce_lr_on_plateau_schedule():

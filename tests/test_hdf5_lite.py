@@ -1,0 +1,84 @@
+"""CPU: the dependency-free HDF5 subset reader / writer (pyrapose_amd/utils/hdf5_lite.py) -- Keras-2.3.1 weight-file layout.
+Round trip through the writer, the structures checked at the offsets the HDF5 File Format Specification gives them, and the
+whole chain file -> name mapping -> engine tensors.  (No libhdf5 exists in this image: files written by h5py itself are
+not covered -- see the module's STATUS note.)"""
+import struct
+
+import numpy as np
+import pytest
+
+from pyrapose_amd.utils import hdf5_lite as H5
+from pyrapose_amd.utils import keras_names as KN
+
+
+def test_round_trip_of_a_keras_layout_file(tmp_path):
+    from pyrapose_amd import arch
+    C = 5
+    W = arch.init_weights(C, seed=3)
+    layers = KN.tensors_to_keras(W, first_auto_index=12, reg_model="model_1", cls_model="model_2")
+    path = str(tmp_path / "resnet50_linemod_03.h5")
+    H5.write_keras_weights(path, layers)
+    with open(path, "rb") as f:
+        raw = f.read()
+    # superblock version 0 at the offsets of the specification (III.A): signature, versions, sizes of offsets / lengths,
+    # base address 0, end-of-file address = file size, root symbol-table entry with cached B-tree / heap addresses
+    assert raw[:8] == b"\x89HDF\r\n\x1a\n" and raw[8] == 0 and raw[13] == 8 and raw[14] == 8
+    base, _, eof, _ = struct.unpack_from("<QQQQ", raw, 24)
+    assert base == 0 and eof == len(raw)
+    name_off, root_hdr, cache, _ = struct.unpack_from("<QQII", raw, 56)
+    btree, heap = struct.unpack_from("<QQ", raw, 80)
+    assert name_off == 0 and cache == 1 and raw[btree:btree + 4] == b"TREE" and raw[heap:heap + 4] == b"HEAP"
+    assert raw[root_hdr] == 1                                   # version-1 object header
+    f = H5.File(path)
+    assert sorted(f.keys()) == sorted(layers.keys())
+    assert f.attrs["keras_version"] == b"2.3.1" and f.attrs["backend"] == b"tensorflow"
+    assert [n.decode() for n in f.attrs["layer_names"]] == list(layers.keys())
+    g = f["model_1"]
+    assert [n.decode() for n in g.attrs["weight_names"]] == list(layers["model_1"].keys())
+    d = f["model_1/conv2d_12/kernel:0"]                         # nested groups for the '/' of weight names
+    assert d.shape == tuple(layers["model_1"]["conv2d_12/kernel:0"].shape)
+    assert np.array_equal(d.read(), layers["model_1"]["conv2d_12/kernel:0"])
+    with pytest.raises(KeyError):
+        f["model_1/nope"]
+    back = H5.read_keras_weights(path)
+    assert list(back.keys()) == list(layers.keys())
+    for lname, ws in layers.items():
+        assert list(back[lname].keys()) == list(ws.keys())
+        for wname, arr in ws.items():
+            got = back[lname][wname]
+            assert got.dtype == np.float32 and np.array_equal(got, np.asarray(arr, np.float32)), (lname, wname)
+    T = KN.keras_to_tensors(back, expected_shapes={k: v.shape for k, v in W.items()})
+    for k in W:
+        assert np.array_equal(T[k], np.asarray(W[k], np.float32)), k
+
+
+def test_model_save_layout_and_chunked_name_lists(tmp_path):
+    """model.save() puts the weights under 'model_weights'; long name lists are split into layer_names0, layer_names1, ..."""
+    layers = {"conv1": {"conv1/kernel:0": np.arange(24, dtype=np.float32).reshape(1, 2, 3, 4)},
+              "bn_conv1": {"bn_conv1/gamma:0": np.ones(4, np.float32), "bn_conv1/moving_variance:0": np.full(4, 2.0, np.float32)},
+              "input_1": {}}
+    path = str(tmp_path / "w.h5")
+    H5.write_keras_weights(path, layers)
+    got = H5.read_keras_weights(path)
+    assert list(got.keys()) == ["conv1", "bn_conv1"] and got["conv1"]["conv1/kernel:0"].shape == (1, 2, 3, 4)
+    assert float(got["bn_conv1"]["bn_conv1/moving_variance:0"][3]) == 2.0
+
+
+def test_other_dtypes_and_big_endian_and_refusals(tmp_path):
+    path = str(tmp_path / "t.h5")
+    H5.write_keras_weights(path, {"l": {"l/a:0": np.arange(6, dtype=np.float64).reshape(2, 3), "l/b:0": np.arange(5, dtype=np.int32),
+                                        "l/c:0": np.float32(7.5)}})
+    got = H5.read_keras_weights(path)["l"]
+    assert got["l/a:0"].dtype == np.float64 and got["l/b:0"].dtype == np.int32 and got["l/c:0"].shape == () and float(got["l/c:0"]) == 7.5
+    with open(path, "rb") as f:
+        raw = bytearray(f.read())
+    raw[8] = 7                                                   # an unknown superblock version is refused, not guessed at
+    bad = str(tmp_path / "bad.h5")
+    with open(bad, "wb") as f:
+        f.write(bytes(raw))
+    with pytest.raises(H5.H5Unsupported):
+        H5.File(bad)
+    with open(bad, "wb") as f:
+        f.write(b"PK\x03\x04 not hdf5")
+    with pytest.raises(ValueError):
+        H5.File(bad)
