@@ -3,7 +3,7 @@
 
 #include "pp_internal.h"
 
-extern "C" const char* pp_version(void) { return "pyrapose_hip 0.3 (gfx950; bf16x3 + f32 MFMA convolutions, sparse 3D-box backward, pose tail)"; }
+extern "C" const char* pp_version(void) { return "pyrapose_hip 0.4 (gfx950; bf16x3 + f32 MFMA convolutions on packed bf16 planes, sparse 3D-box backward, pose tail, device augmentation)"; }
 
 extern "C" int pp_ctx_create(pp_ctx** out, int device, void* hip_stream) {
   if (!out) return PP_ERR_ARG;

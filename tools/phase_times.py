@@ -15,6 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--bench-targets", action="store_true", help="the synthetic annotations of bench.py (SURVEY 8d config 2) instead of a dense positive pattern")
     args = ap.parse_args()
     ctx = ops.Context(0)
     eng = Engine(ctx, 13, args.batch, 480, 640)
@@ -26,6 +27,11 @@ def main():
     eng.y_box[:, ::50, -1] = 1
     eng.y_mask[..., -1] = 1
     eng.y_mask[:, ::7, 2] = 1
+    if args.bench_targets:
+        import bench
+        from pyrapose_amd.utils import anchors as UA
+        _, images, anns = bench.synth_batch(args.batch, 480, 640, 13, seed=1000)
+        eng.set_targets(*UA.anchor_targets_bbox_device(UA.anchors_for_shape_device((480, 640)), images, anns, 13))
     ev = lambda: torch.cuda.Event(enable_timing=True)
     acc = np.zeros(3)
     for it in range(args.steps + 2):
