@@ -45,7 +45,13 @@ def load_model(filepath, backbone_name="resnet50", num_classes=None):
     """models/__init__.py:68-71.  ``filepath`` is an .npz written by ``model.save``; the class count is read from it."""
     import numpy as np
     from .model import PyraPoseModel
-    data = np.load(filepath)
+    with open(filepath, "rb") as f:
+        is_hdf5 = f.read(4) == b"\x89HDF"
+    if is_hdf5:  # a real Keras file: the subset reader + name mapping (utils/hdf5_lite.py, utils/keras_names.py)
+        from ..utils import hdf5_lite, keras_names
+        data = keras_names.keras_to_tensors(hdf5_lite.read_keras_weights(filepath))
+    else:
+        data = np.load(filepath)
     if num_classes is None:
         num_classes = int(data["mask_out/bias"].shape[0])
     m = PyraPoseModel(num_classes, backbone_name.split("_")[0])

@@ -58,6 +58,8 @@ def test_hdf5_is_recognised_by_content_not_by_name(tmp_path):
     model.save_weights(good, format="h5")
     with open(good, "rb") as f:
         assert f.read(4) == b"\x89HDF"
+    m4 = models.load_model(good, backbone_name="resnet50")      # class count read from the file
+    assert m4.num_classes == 2 and np.array_equal(m4.get_weights_dict()["P3/kernel"], model.get_weights_dict()["P3/kernel"])
     m2 = models.backbone("resnet50").retinanet(num_classes=2)
     m2._weights = {k: np.zeros_like(v) for k, v in m2.get_weights_dict().items()}
     m2.load_weights(good)
