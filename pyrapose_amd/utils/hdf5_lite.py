@@ -80,18 +80,18 @@ class _Reader(object):
             n = 1 << (flags & 3)
             size = int.from_bytes(self.b[p:p + n], "little")
             p += n
-            blocks = [(p, size - 0, True)]
+            blocks = [(p, size)]
             track = bool(flags & 4)
             while blocks:
-                p, size, first = blocks.pop(0)
-                end = p + size - (0 if first else 0)
+                p, size = blocks.pop(0)
+                end = p + size
                 q = p
                 while q + 4 <= end:
                     mtype, msize, mflags = self.u8(q), self.u16(q + 1), self.u8(q + 3)
                     q += 4 + (2 if track else 0)
                     if mtype == 0x10:
                         coff, clen = self.u64(q), self.u64(q + 8)
-                        blocks.append((self.base + coff + 4, clen - 8, False))  # skip 'OCHK', drop checksum
+                        blocks.append((self.base + coff + 4, clen - 8))  # skip 'OCHK', drop the checksum
                     else:
                         out.append((mtype, mflags, q, msize))
                     q += msize
@@ -195,13 +195,11 @@ class _Reader(object):
         def walk(node):
             node += self.base
             sig = self.b[node:node + 4]
-            if sig == b"TREE":
-                level, used = self.u8(node + 5), self.u16(node + 6)
+            if sig == b"TREE":  # children of level-0 nodes are symbol-table nodes, of higher levels further B-tree nodes
+                used = self.u16(node + 6)
                 p = node + 24
                 for i in range(used):
-                    child = self.u64(p + 8 + 16 * i)
-                    walk(child)
-                _ = level
+                    walk(self.u64(p + 8 + 16 * i))
             elif sig == b"SNOD":
                 n = self.u16(node + 6)
                 for i in range(n):
