@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
 // 16 B of each plane per row and chunk -- the same bytes as the two f32 quads -- and nothing is converted in the loop.
 // OP: the output tile is written as planes (g_ohi / g_olo; also as f32 when g_out != NULL).
 template <int TM, int TN, bool CAP, bool AP = false, bool OP = false>
-__global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3x_kernel(
+__global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4)) void igemm3x_kernel(
     const IgemmParams p, const void* __restrict__ g_a, const void* __restrict__ g_a1, unsigned a_bytes, const void* __restrict__ g_whi,
     const void* __restrict__ g_wlo, unsigned w_bytes, const float* __restrict__ g_bias, const float* __restrict__ g_addend,
     const float* __restrict__ g_mask, float* __restrict__ g_out, uint2* __restrict__ g_ohi, uint2* __restrict__ g_olo, int w_rows, int w_ld8,
@@ -757,7 +757,9 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3x_kernel(
     s_pitch[i] = (p.tsign * r.SW * p.ld_src * ES) | v;  // ld_src % 4 == 0 -> the pitch is a multiple of 16
   }
   // fragment rows of this lane: wm * 32 * TM + a * 32 + il -> validity bit per tap (9 bits each, two rows per register)
-  unsigned f_valid = 0;
+  unsigned f_valid[(TM + 1) / 2];
+#pragma unroll
+  for (int a = 0; a < (TM + 1) / 2; ++a) f_valid[a] = 0;
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
     const int q = m0 + wm * 32 * TM + a * 32 + il;
@@ -769,7 +771,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3x_kernel(
         const int sy = r.ybase + ty * p.tsign, sx = r.xbase + tx * p.tsign;
         if (q >= 0 && r.ok && (unsigned)sy < (unsigned)r.SH && (unsigned)sx < (unsigned)r.SW) v |= 1u << t;
       }
-    f_valid |= v << (16 * a);
+    f_valid[a >> 1] |= v << (16 * (a & 1));
   }
   int b_base[TN];
 #pragma unroll
@@ -862,22 +864,16 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3x_kernel(
     constexpr int TX = decltype(tx_c)::value;
     const int dx = p.off_x + TX * p.tsign;
     const unsigned tap_bits = (1u << (c_ty * 3 + TX)) * 0x10001u;  // the tap's bit in both 16-bit halves
-    const unsigned okm = f_valid & tap_bits;
+    unsigned okm[(TM + 1) / 2];
+#pragma unroll
+    for (int a = 0; a < (TM + 1) / 2; ++a) okm[a] = f_valid[a] & tap_bits;
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
       const int o = 2 * s + h;
-      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-      for (int a = 0; a < TM; ++a) {
-        const bool ok = ((okm >> (16 * a)) & 0xffffu) != 0;
-        // padded taps read the all-zero slot: one address select per fragment (zeroing the eight fragment registers
-        // instead measured 1 % slower)
-        const int slot = ok ? o * BM + ((wm * 32 * TM + a * 32 + il + dx + 2 * o) & (BM - 1)) : NO * BM;
-        uint4 t = Ahi[slot];
-        ah[a] = *reinterpret_cast<bf16x8*>(&t);
-        t = Alo[slot];
-        al[a] = *reinterpret_cast<bf16x8*>(&t);
-      }
+      // (TM == 4: the gathered fragments are fetched two row blocks at a time, against the same weight fragments -- 16 fewer live
+      // registers, which is what keeps the 256-row tile from spilling)
+      constexpr int AG = TM > 2 ? 2 : TM;
+      bf16x8 bh[TN], bl[TN];
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
         const int slot = o * BN + ((wn * 32 * TN + b * 32 + il + 2 * o) & (BN - 1));
@@ -887,13 +883,29 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void igemm3x_kernel(
         bl[b] = *reinterpret_cast<bf16x8*>(&t);
       }
 #pragma unroll
-      for (int a = 0; a < TM; ++a)
+      for (int a0 = 0; a0 < TM; a0 += AG) {
+        bf16x8 ah[AG], al[AG];
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+        for (int aa = 0; aa < AG; ++aa) {
+          const int a = a0 + aa;
+          const bool ok = ((okm[a >> 1] >> (16 * (a & 1))) & 0xffffu) != 0;
+          // padded taps read the all-zero slot: one address select per fragment (zeroing the eight fragment registers
+          // instead measured 1 % slower)
+          const int slot = ok ? o * BM + ((wm * 32 * TM + a * 32 + il + dx + 2 * o) & (BM - 1)) : NO * BM;
+          uint4 t = Ahi[slot];
+          ah[aa] = *reinterpret_cast<bf16x8*>(&t);
+          t = Alo[slot];
+          al[aa] = *reinterpret_cast<bf16x8*>(&t);
         }
+#pragma unroll
+        for (int aa = 0; aa < AG; ++aa)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) {
+            acc[a0 + aa][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[aa], bh[b], acc[a0 + aa][b], 0, 0, 0);
+            acc[a0 + aa][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[aa], bl[b], acc[a0 + aa][b], 0, 0, 0);
+            acc[a0 + aa][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[aa], bh[b], acc[a0 + aa][b], 0, 0, 0);
+          }
+      }
       // scheduling hint: interleave the LDS fragment reads of this half-step with its MFMAs (measured on the head shapes: +3 %
       // over a plain barrier between the two halves, +1.7 % in the training step; the same hint makes igemm3f's 256x128 tile
       // and the large weight-gradient launches 2 % slower, so it stays here only)
@@ -1377,19 +1389,24 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
                          nullptr);
     return;
   }
-  if constexpr (TM <= 2) {
-    if (igemm3x_ok(p, ahi != nullptr, ohi != nullptr, w_rows, w_ld8)) {
+  {
+    // (the 256-row tile has the tap-row-reuse kernel for plane-stored operands only: its f32 form would need 32 more staging registers)
+    if (igemm3x_ok(p, ahi != nullptr, ohi != nullptr, w_rows, w_ld8) && (TM <= 2 || (ahi != nullptr && !chi))) {
       const int n_tiles_mx = (p.M + BM - 3) / (BM - 2);  // tiles overlap by two rows
       int skip_halo = 0;
       for (int i = 0; i < p.n_seg; ++i) skip_halo = p.seg[i].SW + 1 > skip_halo ? p.seg[i].SW + 1 : skip_halo;
       const dim3 gridx((unsigned)(n_tiles_mx * p.n_tiles_n * splits));
       // with split-K the partial sums go to the f32 scratch and splitk_finish_kernel writes the output (planes included)
       const bool op = ohi != nullptr && splits == 1;
-      if (chi)
-        hipLaunchKernelGGL((igemm3x_kernel<TM, TN, true>), gridx, dim3(256), 0, st, p, (const void*)p.src, nullptr, (unsigned)a_bytes, whi, wlo,
-                           (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)nullptr, (uint2*)nullptr, w_rows, w_ld8, splits, ws,
-                           chi, clo, flags, skip_halo);
-      else if (ahi && op)
+      if constexpr (TM <= 2) {
+        if (chi) {
+          hipLaunchKernelGGL((igemm3x_kernel<TM, TN, true>), gridx, dim3(256), 0, st, p, (const void*)p.src, nullptr, (unsigned)a_bytes, whi, wlo,
+                             (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)nullptr, (uint2*)nullptr, w_rows, w_ld8, splits,
+                             ws, chi, clo, flags, skip_halo);
+          return;
+        }
+      }
+      if (ahi && op)
         hipLaunchKernelGGL((igemm3x_kernel<TM, TN, false, true, true>), gridx, dim3(256), 0, st, p, ahi, alo, (unsigned)a_bytes, whi, wlo,
                            (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)ohi, (uint2*)olo, w_rows, w_ld8, splits, ws, nullptr,
                            nullptr, flags, skip_halo);
@@ -1397,14 +1414,16 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
         hipLaunchKernelGGL((igemm3x_kernel<TM, TN, false, true, false>), gridx, dim3(256), 0, st, p, ahi, alo, (unsigned)a_bytes, whi, wlo,
                            (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)nullptr, (uint2*)nullptr, w_rows, w_ld8, splits, ws,
                            nullptr, nullptr, flags, skip_halo);
-      else if (op)
-        hipLaunchKernelGGL((igemm3x_kernel<TM, TN, false, false, true>), gridx, dim3(256), 0, st, p, (const void*)p.src, nullptr,
-                           (unsigned)a_bytes, whi, wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)ohi, (uint2*)olo, w_rows,
-                           w_ld8, splits, ws, nullptr, nullptr, flags, skip_halo);
-      else
-        hipLaunchKernelGGL((igemm3x_kernel<TM, TN, false>), gridx, dim3(256), 0, st, p, (const void*)p.src, nullptr, (unsigned)a_bytes, whi, wlo,
-                           (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)nullptr, (uint2*)nullptr, w_rows, w_ld8, splits, ws,
-                           nullptr, nullptr, flags, skip_halo);
+      else if constexpr (TM <= 2) {
+        if (op)
+          hipLaunchKernelGGL((igemm3x_kernel<TM, TN, false, false, true>), gridx, dim3(256), 0, st, p, (const void*)p.src, nullptr,
+                             (unsigned)a_bytes, whi, wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)ohi, (uint2*)olo,
+                             w_rows, w_ld8, splits, ws, nullptr, nullptr, flags, skip_halo);
+        else
+          hipLaunchKernelGGL((igemm3x_kernel<TM, TN, false>), gridx, dim3(256), 0, st, p, (const void*)p.src, nullptr, (unsigned)a_bytes, whi,
+                             wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)nullptr, (uint2*)nullptr, w_rows, w_ld8, splits,
+                             ws, nullptr, nullptr, flags, skip_halo);
+      }
       return;
     }
   }
@@ -1465,7 +1484,8 @@ static void pick_tile3(const pp_ctx* ctx, int M, int Nout, int ld_out, int n_ste
   // the 256x128 tile has no tap-row-reuse variant: where that kernel applies, 128x128 with reuse wins (measured on the
   // 256-channel class head, 50400 rows: 194-207 us against 205-227 us; a reuse bonus inside the model above instead sent
   // that shape to 64x128 and the step lost 2 %)
-  if (x_ok && *tm == 4 && *splits == 1) {
+  static const bool x4 = []() { const char* e = getenv("PP_CONV3_X4"); return e && e[0] == '1'; }();
+  if (x_ok && *tm == 4 && *splits == 1 && !x4) {
     *tm = 2;
     *tn = 2;
   }
