@@ -784,7 +784,13 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
   float4 ra[TM][2];
   uint4 rah[TM], ral[TM];
   uint4 rbh[TN], rbl[TN];
-  int ty = g_begin / n_chunks, chunk = g_begin - ty * n_chunks;  // group being LOADED
+  // group g <-> (chunk, ty).  Default (p.x_ty_inner, PP_CONV3_X_ORDER=1): kernel row innermost -- the three row-shifted tiles of
+  // one channel chunk are fetched back to back (they overlap by all but one image row, so the second and third come from
+  // L1 / L2 while they are hot): same time, FETCH_SIZE -10 % on the 512-wide head conv and -40 % on the 256-wide one
+  // (profiles/r02_traffic.json).  PP_CONV3_X_ORDER=0: channel chunk innermost (round 1).
+  const bool ty_inner = p.x_ty_inner != 0;
+  int ty = ty_inner ? g_begin % p.kh : g_begin / n_chunks;
+  int chunk = ty_inner ? g_begin / p.kh : g_begin - ty * n_chunks;  // group being LOADED
 
   auto load_a = [&]() {
 #pragma unroll
@@ -948,10 +954,17 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
     // tx = 2: the next group's gathered rows and its first weight tile are fetched, converted and written
     {
       const bool more = g + 1 < g_end;  // past the end: rewind to group 0 (a harmless re-load)
-      chunk += 1;
-      const bool wc = chunk == n_chunks;
-      chunk = wc ? 0 : chunk;
-      ty += wc ? 1 : 0;
+      if (ty_inner) {
+        ty += 1;
+        const bool wt = ty == p.kh;
+        ty = wt ? 0 : ty;
+        chunk += wt ? 1 : 0;
+      } else {
+        chunk += 1;
+        const bool wc = chunk == n_chunks;
+        chunk = wc ? 0 : chunk;
+        ty += wc ? 1 : 0;
+      }
       chunk = more ? chunk : 0;
       ty = more ? ty : 0;
     }
@@ -1396,6 +1409,8 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
       int skip_halo = 0;
       for (int i = 0; i < p.n_seg; ++i) skip_halo = p.seg[i].SW + 1 > skip_halo ? p.seg[i].SW + 1 : skip_halo;
       const dim3 gridx((unsigned)(n_tiles_mx * p.n_tiles_n * splits));
+      static const int x_order = []() { const char* e = getenv("PP_CONV3_X_ORDER"); return e ? atoi(e) : 1; }();
+      p.x_ty_inner = x_order;
       // with split-K the partial sums go to the f32 scratch and splitk_finish_kernel writes the output (planes included)
       const bool op = ohi != nullptr && splits == 1;
       if constexpr (TM <= 2) {

@@ -46,6 +46,7 @@ struct IgemmParams {
   const void* add_hi;
   const void* add_lo;
   const void* mask_hi;
+  int x_ty_inner;  // igemm3x: loop order of the (kernel row, channel chunk) groups
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8, each with a private L2).
