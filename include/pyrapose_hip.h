@@ -56,7 +56,9 @@ int pp_ctx_set_split_capture(pp_ctx* ctx, void* hi, void* lo);
  * stays so layer after layer, dilated by one pixel per 3x3 conv).  pp_row_block_list scans a gradient tensor x [rows][ld]
  * (first `cols` columns) once: flags[b] = 1 when the 32-row block b holds a non-zero (or a NaN), list = {count, the flagged
  * block indices ascending}.  With nb = ceil(rows/32): flags holds 2 nb bytes and list 2 (nb + 1) ints of device memory --
- * the first halves are the result, the second halves scratch of the bwd-data launch that takes the hint.
+ * the first halves are the result, the second halves scratch of the bwd-data launch that takes the hint (after that launch the
+ * second nb bytes of `flags` flag every block of dx that may hold a non-zero: the dilated blocks, or all of them when the
+ * launch ran dense; without an addend dx is zero in the others -- pp_row_block_list_planes_within takes that as `within`).
  * pp_ctx_set_row_block_skip is one-shot: the NEXT pp_conv2d_nhwc_bwd_weight_bf16x3 call on this context (float32 operands)
  * reduces over the listed blocks of dy only; the NEXT pp_conv2d_nhwc_bwd_data_bf16x3 call (3x3, stride 1, pad 1) computes
  * only the 32-row blocks of dx that a flagged block of dy can reach (dilated by one pixel in 2-D, compacted four to a tile)
@@ -67,6 +69,11 @@ int pp_ctx_set_split_capture(pp_ctx* ctx, void* hi, void* lo);
 int pp_row_block_list(pp_ctx* ctx, const float* x, int rows, int ld, int cols, unsigned char* flags, int* list);
 /* the same scan of a tensor stored as bf16 (hi, lo) planes ([rows][ld] each) */
 int pp_row_block_list_planes(pp_ctx* ctx, const void* x_hi, const void* x_lo, int rows, int ld, int cols, unsigned char* flags, int* list);
+/* the same, reading only the blocks flagged in `within` ([n_blocks] bytes; NULL = all): for a tensor the caller knows to be zero
+ * elsewhere -- the data gradient a row-block-skip launch has just written is zero outside the blocks that launch listed (the
+ * second n_blocks bytes of ITS flags buffer), so the scan for the next layer reads 10-25 % of the tensor instead of all of it. */
+int pp_row_block_list_planes_within(pp_ctx* ctx, const void* x_hi, const void* x_lo, int rows, int ld, int cols, const unsigned char* within,
+                                    unsigned char* flags, int* list);
 /* One-shot: the NEXT pp_conv2d_nhwc_fwd_bf16x3 (residual) / pp_conv2d_nhwc_bwd_data_bf16x3 (addend, relu_src) call on this
  * context reads those epilogue operands from bf16 (hi, lo) planes instead of float32 tensors -- the storage format of every
  * activation and gradient a bf16x3 conv produces when its output is requested as planes only (value = hi + lo, 4 bytes per

@@ -93,6 +93,7 @@ _SIGS = {
     "pp_row_block_list": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "pp_ctx_set_row_block_skip": (_i, [_p, _p, _p]),
     "pp_row_block_list_planes": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
+    "pp_row_block_list_planes_within": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p]),
     "pp_ctx_set_epilogue_planes": (_i, [_p, _p, _p, _p]),
     "pp_add_n_v": (_i, [_p, _sz, C.POINTER(TView), C.POINTER(TView), C.POINTER(TView), C.POINTER(TView)]),
     "pp_relu_fwd_v": (_i, [_p, _sz, C.POINTER(TView), C.POINTER(TView)]),

@@ -1079,9 +1079,14 @@ __global__ void row_block_flags_kernel(const float* __restrict__ x, int rows, in
 }
 
 // the same scan of a tensor stored as bf16 (hi, lo) planes: value != 0 <=> a magnitude bit is set in hi or lo
+// within (may be NULL): only the blocks flagged there can hold a non-zero (the caller knows the others are zero): they are not read
 __global__ void row_block_flags_planes_kernel(const uint2* __restrict__ hi, const uint2* __restrict__ lo, int rows, int ld4, int cols4,
-                                              unsigned char* __restrict__ flags) {
+                                              unsigned char* __restrict__ flags, const unsigned char* __restrict__ within) {
   const int blk = blockIdx.x, r0 = blk * 32;
+  if (within && !within[blk]) {  // (uniform)
+    if (threadIdx.x == 0) flags[blk] = 0;
+    return;
+  }
   const int nr = rows - r0 < 32 ? rows - r0 : 32;
   int any = 0;
   for (int i = threadIdx.x; i < nr * cols4; i += blockDim.x) {
@@ -1130,15 +1135,22 @@ extern "C" int pp_row_block_list(pp_ctx* ctx, const float* x, int rows, int ld, 
   return PP_OK;
 }
 
+extern "C" int pp_row_block_list_planes_within(pp_ctx* ctx, const void* x_hi, const void* x_lo, int rows, int ld, int cols,
+                                               const unsigned char* within, unsigned char* flags, int* list);
 extern "C" int pp_row_block_list_planes(pp_ctx* ctx, const void* x_hi, const void* x_lo, int rows, int ld, int cols, unsigned char* flags,
                                         int* list) {
+  return pp_row_block_list_planes_within(ctx, x_hi, x_lo, rows, ld, cols, nullptr, flags, list);
+}
+
+extern "C" int pp_row_block_list_planes_within(pp_ctx* ctx, const void* x_hi, const void* x_lo, int rows, int ld, int cols,
+                                               const unsigned char* within, unsigned char* flags, int* list) {
   PP_REQUIRE_CTX(ctx);
   PP_CHECK_ARG(ctx, x_hi && x_lo && flags && list && rows > 0 && cols > 0 && cols <= ld && ld % 8 == 0 && pp_is_packed(x_hi, x_lo), PP_ERR_ARG,
                "pp_row_block_list_planes: bad tensor (ld %% 8 == 0, packed planes)");
   const int nb = (rows + 31) / 32, cols4 = (cols + 3) / 4;
   PP_CHECK_ARG(ctx, 4 * cols4 <= ld, PP_ERR_SHAPE, "pp_row_block_list_planes: cols rounded up to 4 exceed ld");
   hipLaunchKernelGGL(row_block_flags_planes_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const uint2*)x_hi, (const uint2*)x_lo, rows,
-                     ld / 4, cols4, flags);
+                     ld / 4, cols4, flags, within);
   hipLaunchKernelGGL(row_block_compact_kernel, dim3(1), dim3(256), 0, ctx->stream, (const unsigned char*)flags, nb, list);
   PP_CHECK_LAUNCH(ctx, "pp_row_block_list_planes");
   return PP_OK;
@@ -1368,8 +1380,14 @@ static void launch_igemm3_rowlist(hipStream_t st, IgemmParams& p, const void* ah
     hipLaunchKernelGGL((igemm3f_kernel<TM, TN, false, false, false, true>), grid, dim3(256), 0, st, p, (const void*)p.src, nullptr,
                        (unsigned)a_bytes, whi, wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)nullptr, (uint2*)nullptr,
                        w_rows, w_ld8, 1, (float*)nullptr, (const int*)out_list);
-  hipLaunchKernelGGL(rl_fill_kernel, dim3((unsigned)nb), dim3(256), 0, st, p, (const unsigned char*)out_flags, p.addend, p.mask_src, p.out, ohi,
-                     olo);
+  // In place on the addend (dx == the running sum of the other data gradients of this tensor, no ReLU mask): the rows that no
+  // non-zero reaches already hold their value -- nothing to fill (the shared pyramid features' gradient: 103 MB not moved).
+  const bool in_place = (ohi != nullptr && p.add_hi == (const void*)ohi && p.ld_add == p.ld_out && !p.out && !p.addend && !p.mask_hi &&
+                         !p.mask_src && !p.relu) ||
+                        (p.out != nullptr && p.addend == p.out && p.ld_add == p.ld_out && !ohi && !p.add_hi && !p.mask_hi && !p.mask_src && !p.relu);
+  if (!in_place)
+    hipLaunchKernelGGL(rl_fill_kernel, dim3((unsigned)nb), dim3(256), 0, st, p, (const unsigned char*)out_flags, p.addend, p.mask_src, p.out, ohi,
+                       olo);
 }
 
 static void split_capture_pass(hipStream_t st, const IgemmParams& p, void* chi, void* clo) {
@@ -1668,6 +1686,19 @@ extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d
                PP_ERR_ARG, "pp_conv2d_nhwc_bwd_data_bf16x3: output planes");
   static const bool s2_classes = []() { const char* e = getenv("PP_CONV3_S2CLASSES"); return !(e && e[0] == '0'); }();
   const bool all_f32 = dy && dx && !dy_hi && !dx_hi, all_planes = dy_hi && dx_hi && !dx;  // (the parity-class / row-list kernels exist for these two)
+  // Row-block skip: does the launch over the LISTED blocks (launch_igemm3_rowlist below) apply?  PP_SPARSE_DGRAD: 22 (default)
+  // / 12 = tile of that launch (equal within noise on the bench step), 0 = keep the dense grid and skip the k-loop of tiles
+  // that see no flagged block (coarser: a 126-row tile spans 1.6 image rows)
+  static const int rl_mode = []() { const char* e = getenv("PP_SPARSE_DGRAD"); return e ? atoi(e) : 22; }();
+  bool rl_ok = skip_flags && skip_scratch_ok && rl_mode && (all_f32 || all_planes) && !chi && d->stride == 1 && d->kh == 3 && d->kw == 3 &&
+               d->pad_t == 1 && d->pad_l == 1 && p.bias == nullptr && igemm3_fast_ok(p, all_planes, d->cin, cred / 8);
+  for (int i = 0; i < p.n_seg && rl_ok; ++i)
+    rl_ok = p.seg[i].OH == p.seg[i].SH && p.seg[i].OW == p.seg[i].SW && p.seg[i].row_begin == p.seg[i].src_row_begin;
+  // Contract of the hint's scratch (pp_row_block_list_planes_within relies on it): after this call the second n_blocks bytes
+  // of the flags buffer flag every 32-row block of dx that may hold a non-zero -- the dilated list when the listed launch
+  // runs, everything otherwise.
+  if (skip_scratch_ok && !rl_ok)
+    PP_HIP(ctx, hipMemsetAsync(const_cast<unsigned char*>(skip_flags) + (p.M + 31) / 32, 1, (size_t)((p.M + 31) / 32), ctx->stream));
   if (d->stride == 2 && s2_classes && (all_f32 || all_planes) && d->in.n_seg == 1) {
     // Stride-2 bwd-data as four stride-1 launches, one per parity class (cy, cx) of the input grid: input cell
     // (2y'+cy, 2x'+cx) only receives the taps ty = ty0 + 2i with ty0 = (cy + pad_t) & 1 (x alike), from output cell
@@ -1713,25 +1744,16 @@ extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d
       return PP_OK;
     }
   }
-  if (skip_flags && skip_scratch_ok && (all_f32 || all_planes) && !chi && d->stride == 1 && d->kh == 3 && d->kw == 3 && d->pad_t == 1 &&
-      d->pad_l == 1 && p.bias == nullptr && igemm3_fast_ok(p, all_planes, d->cin, cred / 8)) {
-    bool same = true;
-    for (int i = 0; i < p.n_seg && same; ++i)
-      same = p.seg[i].OH == p.seg[i].SH && p.seg[i].OW == p.seg[i].SW && p.seg[i].row_begin == p.seg[i].src_row_begin;
-    // PP_SPARSE_DGRAD: 22 (default) / 12 = tile of the listed-block launch (equal within noise on the bench step), 0 = keep
-    // the dense grid and skip the k-loop of tiles that see no flagged block (coarser: a 126-row tile spans 1.6 image rows)
-    static const int rl_mode = []() { const char* e = getenv("PP_SPARSE_DGRAD"); return e ? atoi(e) : 22; }();
-    if (same && rl_mode) {
-      const int nb = (p.M + 31) / 32;
-      unsigned char* out_flags = const_cast<unsigned char*>(skip_flags) + nb;
-      int* out_list = const_cast<int*>(skip_list_in) + nb + 1;
-      if (rl_mode == 22)
-        launch_igemm3_rowlist<2, 2>(ctx->stream, p, dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8, dx_hi, dx_lo, skip_flags, out_flags, out_list);
-      else
-        launch_igemm3_rowlist<1, 2>(ctx->stream, p, dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8, dx_hi, dx_lo, skip_flags, out_flags, out_list);
-      PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_data_bf16x3");
-      return PP_OK;
-    }
+  if (rl_ok) {
+    const int nb = (p.M + 31) / 32;
+    unsigned char* out_flags = const_cast<unsigned char*>(skip_flags) + nb;
+    int* out_list = const_cast<int*>(skip_list_in) + nb + 1;
+    if (rl_mode == 22)
+      launch_igemm3_rowlist<2, 2>(ctx->stream, p, dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8, dx_hi, dx_lo, skip_flags, out_flags, out_list);
+    else
+      launch_igemm3_rowlist<1, 2>(ctx->stream, p, dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8, dx_hi, dx_lo, skip_flags, out_flags, out_list);
+    PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_data_bf16x3");
+    return PP_OK;
   }
   dispatch3(ctx, p, dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8, dx_hi, dx_lo, chi, clo, skip_flags);
   PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_data_bf16x3");

@@ -85,10 +85,11 @@ def _view(t, pl):
 
 class Grad(object):
     """A gradient matrix: float32 (`t`) and / or bf16 planes (`pl`); rows(a, b) = the same for a row range."""
-    __slots__ = ("t", "pl")
+    __slots__ = ("t", "pl", "within")
 
     def __init__(self, t, pl=None):
         self.t, self.pl = t, pl
+        self.within = None  # uint8 flags of the only 32-row blocks that can hold a non-zero (a sparse data gradient without addend)
 
     def rows(self, r0, r1):
         return Grad(None if self.t is None else self.t[r0:r1], None if self.pl is None else (self.pl[0][r0:r1], self.pl[1][r0:r1]))
@@ -696,9 +697,13 @@ class Engine(object):
             mask = act if (act.relu and last) else None
             pl = op.get("planes")
             if pl is not None and pl["dg_hi"] is not None:
-                out = self._new_grad(act.rows, act.ld)
                 gcap = op.get("g_cap")
                 sk = op.get("skip")
+                # a sparse data gradient (row-block skip) that only adds to the sum of the earlier ones works in place on that sum:
+                # the rows no non-zero reaches keep their value and nothing else is moved (`acc` of i > 0 is private to this loop)
+                in_place = (sk is not None and i > 0 and mask is None and acc is not None and gcap is None
+                            and _os.environ.get("PP_SPARSE_INPLACE", "1") != "0")
+                out = acc if in_place else self._new_grad(act.rows, act.ld)
                 # every operand in the format it exists in (planes where there is no float32 copy)
                 dy_t, dy_pl = (None, gy.pl) if gy.pl is not None else (gy.t, None)
                 a_t = a_pl = m_t = m_hi = None
@@ -712,6 +717,8 @@ class Engine(object):
                                        m_hi=m_hi, out=out, gcap=gcap, sk=sk:
                                        ops.conv_bwd_data3(ctx, d, dy_t, dh, dl, a_t, m_t, out.t, dy_pl, out.pl, gcap, sk, a_pl, m_hi), "conv_dgrad",
                                        op["spec"].name, op["flops"]))
+                # a row-block-skip launch without addend leaves zeros outside the blocks it flags in the second half of its scratch
+                out.within = sk[0][sk[0].numel() // 2:] if (sk is not None and acc is None and _os.environ.get("PP_SPARSE_WITHIN", "1") != "0") else None
                 pw = op.pop("pending_wgrad", None)
                 if pw is not None:  # the layer's weight gradient reads the planes this launch has just written
                     self.bwd_ops.append(pw)
@@ -758,7 +765,8 @@ class Engine(object):
                         self.bwd_ops.append(Op(lambda gt=g.t, cols=cols, skip=skip: ops.row_block_list(ctx, gt, cols, skip[0], skip[1]),
                                                "pointwise", "rowblocks:" + s.name))
                     else:
-                        self.bwd_ops.append(Op(lambda gp=g.pl, cols=cols, skip=skip: ops.row_block_list_planes(ctx, gp, cols, skip[0], skip[1]),
+                        self.bwd_ops.append(Op(lambda gp=g.pl, cols=cols, skip=skip, within=g.within:
+                                               ops.row_block_list_planes(ctx, gp, cols, skip[0], skip[1], within),
                                                "pointwise", "rowblocks:" + s.name))
                 if s.trainable:
                     dw = P.view(P.grad, s.name + "/kernel")

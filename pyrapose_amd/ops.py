@@ -155,12 +155,18 @@ def row_block_list(ctx, x, cols, flags=None, blocks=None):
     return flags, blocks
 
 
-def row_block_list_planes(ctx, planes, cols, flags, blocks):
-    """pp_row_block_list_planes: the same scan of a tensor stored as bf16 (hi, lo) planes [rows, ld]"""
+def row_block_list_planes(ctx, planes, cols, flags, blocks, within=None):
+    """pp_row_block_list_planes(_within): the same scan of a tensor stored as bf16 (hi, lo) planes [rows, ld]; within = uint8 flags of
+    the only blocks that can hold a non-zero (the others are not read)"""
     hi, lo = planes
     rows = hi.shape[0]
-    check(lib.pp_row_block_list_planes(ctx.handle, _ptr(hi), _ptr(lo), rows, planes_ld(planes), int(cols), _ptr(flags), _ptr(blocks)), ctx.handle,
-          "pp_row_block_list_planes")
+    if within is not None:
+        assert within.dtype == torch.uint8 and within.is_contiguous() and within.numel() >= (rows + 31) // 32
+        check(lib.pp_row_block_list_planes_within(ctx.handle, _ptr(hi), _ptr(lo), rows, planes_ld(planes), int(cols), _ptr(within), _ptr(flags),
+                                                  _ptr(blocks)), ctx.handle, "pp_row_block_list_planes_within")
+    else:
+        check(lib.pp_row_block_list_planes(ctx.handle, _ptr(hi), _ptr(lo), rows, planes_ld(planes), int(cols), _ptr(flags), _ptr(blocks)),
+              ctx.handle, "pp_row_block_list_planes")
     return flags, blocks
 
 

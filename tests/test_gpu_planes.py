@@ -201,6 +201,32 @@ def test_planes_only_row_block_skip(ctx, frac):
                        relu_src_hi=mp[0])
     assert float((merged(dxp) - dx0).abs().max()) <= 2e-5 * float(dx0.abs().max())
     assert not bool(f2[nb: 2 * nb].all())  # some blocks were filled, not computed
+    # in place on the addend (no ReLU mask): the rows no non-zero reaches are not touched at all, the others get the same sum
+    dx1 = torch.full((rows, cin), float("nan"), device="cuda")
+    ops.conv_bwd_data3(ctx, d, dy, dh, dl, add, None, dx1)
+    acc = split(ctx, add)
+    ops.conv_bwd_data3(ctx, d, None, dh, dl, None, None, None, dy_planes=gp, dx_planes=acc, dy_skip=(f2, b2), addend_planes=acc)
+    assert float((merged(acc) - dx1).abs().max()) <= 2e-5 * float(dx1.abs().max())
+    # without an addend the result is zero outside the blocks the launch flagged in the second half of its scratch: a scan
+    # restricted to those blocks (pp_row_block_list_planes_within) finds what the full scan finds
+    dxz = nan_planes(dx0)
+    ops.conv_bwd_data3(ctx, d, None, dh, dl, None, None, None, dy_planes=gp, dx_planes=dxz, dy_skip=(f2, b2), relu_src_hi=mp[0])
+    within = f2[nb: 2 * nb].clone()
+    fa, ba = torch.zeros_like(flags), torch.zeros_like(blocks)
+    fb, bb = torch.zeros_like(flags), torch.zeros_like(blocks)
+    ops.row_block_list_planes(ctx, dxz, cin, fa, ba)
+    ops.row_block_list_planes(ctx, dxz, cin, fb, bb, within=within)
+    assert torch.equal(fa[:nb], fb[:nb]) and torch.equal(ba[: nb + 1], bb[: nb + 1])
+    assert not bool((fa[:nb].bool() & ~within.bool()).any())
+    # a launch that takes the hint but cannot run over the listed blocks (here: 1x1) flags every block as possibly non-zero
+    d1 = ops.make_conv_desc(B, shapes, shapes, cin, cout, 1, 1, 0, 0, cin, cout, cout)
+    w1h, w1l = torch.zeros((1, cout, cin), **i16), torch.zeros((1, cout, cin), **i16)
+    d1h, d1l = torch.zeros((1, cin, cout), **i16), torch.zeros((1, cin, cout), **i16)
+    ops.conv_split_weights3(ctx, d1, w[:cin].contiguous(), w1h, w1l, d1h, d1l)
+    f3, b3 = f2.clone(), b2.clone()
+    f3[nb:] = 0
+    ops.conv_bwd_data3(ctx, d1, None, d1h, d1l, None, None, None, dy_planes=gp, dx_planes=nan_planes(dx0), dy_skip=(f3, b3))
+    assert bool(f3[nb: 2 * nb].all())
     dw0, dw1 = torch.zeros_like(w), torch.zeros_like(w)
     db0, db1 = torch.zeros((cout,), device="cuda"), torch.zeros((cout,), device="cuda")
     ops.conv_bwd_weight3(ctx, d, x, dy, dw0, db0)
