@@ -274,6 +274,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--dump-ops", default=None, help="write a per-launch table (name, kind, GFLOP, avg us, TFLOP/s)")
     ap.add_argument("--no-inference", action="store_true", help="skip the config-3 inference leg (B=32, C=8)")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="with PP_PREFETCH=1 (engine built with a prefix lane): do not use the look-ahead -- the frozen prefix (conv1 + res2) "
+                         "of a batch runs inside its own step instead of beside the previous one.  Without PP_PREFETCH=1 (default) there is no look-ahead.")
     return ap.parse_args(argv)
 
 
@@ -353,6 +356,8 @@ def main_worker(args):
             out[op["spec"].name] = {"wgrad": float(both[:nb].mean()), "dgrad": float(both[nb:].mean())}
         return out
 
+    pf_flags = []  # per run(): did the steps use the look-ahead?
+
     def run(mode, steps, warmup, events, dump_ops=None, sparse=None):
         """Build an engine in `mode`, run warmup + timed steps, return (dt, images, losses, roofline dict)."""
         if sparse is not None:
@@ -364,8 +369,13 @@ def main_worker(args):
         eng.set_targets(y_box, y_cls, y_mask)
         eng.x_in.copy_(x_dev)
         torch.cuda.synchronize()
+        # look-ahead (opt-in: PP_PREFETCH=1; engine.py, prefix lane): conv1 + res2 are frozen (bin/train.py:72-78, models/resnet.py:87-110), so their
+        # output for batch i+1 does not depend on step i's update and is computed beside step i's trunk on a stream of its
+        # own -- ONE prefix per step either way (the last timed step computes the one of a batch that never comes)
+        nx = eng.RESIDENT if (eng.prefix_lane is not None and not args.no_prefetch) else None
+        pf_flags.append(nx is not None)
         for _ in range(warmup):
-            eng.train_step()
+            eng.train_step(next_x=nx)
         records = []
         # per-launch events cost CPU time (the launch loop must stay ahead of the GPU): they are recorded on every
         # EVENT_EVERY-th timed step only, from pools created before the timed region
@@ -398,7 +408,7 @@ def main_worker(args):
         for i in range(steps):
             sample[0] = (i // every) if (events and i % every == 0) else -1
             n_sampled += int(sample[0] >= 0)
-            eng.train_step()
+            eng.train_step(next_x=nx)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -473,6 +483,7 @@ def main_worker(args):
         return dt, steps * B * world, losses, roof, mode_used
 
     dt, images_total, losses, roof, mode = run(args.conv_mode, args.steps, args.warmup, not args.no_kernel_events, args.dump_ops)
+    prefetch_used = pf_flags[0]
 
     if rank != 0:
         if world > 1:
@@ -547,6 +558,9 @@ def main_worker(args):
         "rccl_ranks": (world if backend == "nccl" else 0), "dist_backend": backend,
         "value_dense_backward": ((sparse or {}).get("dense_backward") or {}).get("value"),
         "dtype": "bf16x3" if mode == "bf16x3" else "f32", "data": "synthetic", "sparse_backward": sparse,
+        "pipeline": ("software-pipelined over steps: the frozen prefix (conv1 + res2, no trainable weight) of batch i+1 runs on its own "
+                     "stream beside batch i; every step executes one prefix, one trunk + heads forward, one backward, one optimizer "
+                     "update (--no-prefetch: everything of a batch inside its own step)") if prefetch_used else "none",
         "dtype_note": ("every conv product = x_hi*w_hi + x_hi*w_lo + x_lo*w_hi on bf16 MFMA with f32 accumulation (2^-16 relative); "
                        "activations, master weights, losses and Adam in float32; head outputs within 1e-3 of the float64 oracle "
                        "(tests/test_gpu_model.py)") if mode == "bf16x3" else "exact f32 MFMA (v_mfma_f32_32x32x2_f32) everywhere",

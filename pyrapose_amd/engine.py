@@ -294,6 +294,25 @@ class Engine(object):
                 c.set_workspace(ws_mb << 20)
         self._lane = 0
         self.trunk_lanes = os.environ.get("PP_TRUNK_LANES", "1") != "0"  # backbone shortcut / FPN level 4-5 chains on lane 1
+        # Prefix lane (training with conv1 + res2 frozen, the reference's setting): the frozen prefix is a pure function of
+        # the input batch -- no weight of it ever changes -- so the prefix of batch i+1 can run while batch i is still in
+        # its trunk / heads (forward(next_x=...): software pipelining over steps; the trunk's launches are small and leave
+        # most of the chip idle, the prefix is HBM-bound).  Its launches get a stream and a native context of their own; all but the LAST of them (res2c_branch2c, which writes the tensor that res3a's weight
+        # gradients read until the end of the step) only touch buffers that nothing else reads.  Opt-in (PP_PREFETCH=1): bit-identical
+        # results (tests/test_gpu_prefetch.py), but the bench step gains only 0.5-1 % -- the HBM-bound prefix raises the memory latency
+        # that the trunk's small launches are bound by, and released later (beside the heads or the backward: PP_PREFETCH_AFTER) it
+        # gains nothing.  Default: the prefix is part of lane 0.
+        self.prefix_lane = None
+        self.n_prefix_early = 0
+        self._prefetched = None
+        frozen_prefix = all(not sp.trainable for sp in self.specs if sp.name == "conv1" or sp.name.startswith("res2"))
+        if self.train and frozen_prefix and self.conv_mode == "bf16x3" and os.environ.get("PP_PREFETCH", "0") == "1":
+            pst = torch.cuda.Stream(device=ctx.device)
+            self.streams.append(pst)
+            self.ctxs.append(ops.Context(ctx.device, pst))
+            if ws_mb > 0:
+                self.ctxs[-1].set_workspace(ws_mb << 20)  # (same launch choices -- split-K at small sizes -- as on lane 0: same bits)
+            self.prefix_lane = len(self.streams) - 1
         self.acts = OrderedDict()
         self.step_count = 0
         self._build_forward()
@@ -324,6 +343,10 @@ class Engine(object):
         if opt is not None:
             opt.close()
             self.opt = None
+        st = getattr(self, "streams", None)
+        if st and getattr(self, "ctxs", None):
+            for side in st[1:]:  # (a prefetched prefix may still be running: the buffers are freed in lane 0's order)
+                st[0].wait_stream(side)
         for c in getattr(self, "ctxs", []):
             c.close()
         self.ctxs = []
@@ -460,6 +483,9 @@ class Engine(object):
         B, H, W = self.B, self.H, self.W
         ctx = self.ctx
         self.x_in = torch.zeros((B, H, W, 3), dtype=torch.float32, device="cuda")
+        if self.prefix_lane is not None:
+            self._lane = self.prefix_lane
+        pctx = self.ctxs[self._lane]  # the context of the frozen prefix's launches (lane 0, or the prefix lane)
         # (the row-as-tap stem needs the buffer-addressed loop: PP_CONV3_FAST=0 also turns it off)
         self.stem3 = (self.conv_mode == "bf16x3" and _os.environ.get("PP_STEM3", "1") != "0" and
                       _os.environ.get("PP_CONV3_FAST", "1") != "0")
@@ -469,17 +495,17 @@ class Engine(object):
             Hp, Wp = H + 6, (W + 8 + 1) // 2 * 2
             self.stem_frame = (Hp, Wp)
             x4 = self._new_act("input4", [(Hp, Wp)], 4)
-            self._push(Op(lambda: ops.pack_rgb_to_4_padded(ctx, self.x_in, x4.t, Hp, Wp), "pointwise", "pack_rgb"), (), x4)
+            self._push(Op(lambda: ops.pack_rgb_to_4_padded(pctx, self.x_in, x4.t, Hp, Wp), "pointwise", "pack_rgb", lane=self._lane), (), x4)
             y = self._build_stem3(x4)
         else:
             x4 = self._new_act("input4", [(H, W)], 4)
-            self._push(Op(lambda: ops.pack_rgb_to_4(ctx, self.x_in, x4.t), "pointwise", "pack_rgb"), (), x4)
+            self._push(Op(lambda: ops.pack_rgb_to_4(pctx, self.x_in, x4.t), "pointwise", "pack_rgb", lane=self._lane), (), x4)
             y = self._conv("conv1", x4, relu=True)
         (h1, w1) = y.shapes[0]
         ph, pw = (h1 + 1) // 2, (w1 + 1) // 2
         pool = self._new_act("pool1", [(ph, pw)], 64)
         c1 = y
-        self._push(Op(lambda: ops.maxpool3x3s2(ctx, B, h1, w1, 64, c1.t, ph, pw, pool.t), "pointwise", "pool1"), (c1,), pool)
+        self._push(Op(lambda: ops.maxpool3x3s2(pctx, B, h1, w1, 64, c1.t, ph, pw, pool.t), "pointwise", "pool1", lane=self._lane), (c1,), pool)
         self.graph_ops.append(dict(kind="stop"))
         y = pool
         blocks = arch.BACKBONE_BLOCKS[self.backbone]
@@ -491,10 +517,16 @@ class Engine(object):
                 a = self._conv(pre + "_branch2a", y, relu=True)
                 b = self._conv(pre + "_branch2b", a, relu=True)
                 if block == 0:
-                    with self._on(1):  # the projection shortcut runs beside the 2a -> 2b chain
+                    if self._lane == self.prefix_lane:  # (the prefix is one chain on its own stream)
                         sc = self._conv(pre + "_branch1", y)
+                    else:
+                        with self._on(1):  # the projection shortcut runs beside the 2a -> 2b chain
+                            sc = self._conv(pre + "_branch1", y)
                 else:
                     sc = y
+                if stage == 0 and block == n_blocks - 1 and self.prefix_lane is not None:
+                    self.n_prefix_early = len(self.fwd_ops)  # the launches before this one never touch what the rest of the step reads
+                    self._lane = 0
                 y = self._conv(pre + "_branch2c", b, out_name=pre, relu=True, residual=sc)
             stage_out.append(y)
         C3, C4, C5 = stage_out[1], stage_out[2], stage_out[3]
@@ -530,6 +562,14 @@ class Engine(object):
                     mixed.append(c[i])
         self.fwd_ops = trunk + mixed
         self._link_lanes()
+        # where in the forward plan the next batch's prefix is released (after the launch of that name; default: as soon as this
+        # batch's own prefix has been consumed)
+        self.pf_trigger = self.n_prefix_early + 1
+        after = _os.environ.get("PP_PREFETCH_AFTER")
+        if after and self.prefix_lane is not None:
+            idx = [i for i, o in enumerate(self.fwd_ops) if o.name == after and o.lane == 0]
+            assert idx, "PP_PREFETCH_AFTER=%s: no such lane-0 launch" % after
+            self.pf_trigger = max(self.pf_trigger, idx[0] + 1)
 
     def _build_stem3(self, x4):
         B, H, W = self.B, self.H, self.W
@@ -543,12 +583,12 @@ class Engine(object):
         d.kw = 1  # 7 kernel rows x (7 taps x 4 channels -> 32)
         self._stem = dict(desc=d, w=torch.zeros((7 * 32, _ru(s.cout, 16)), dtype=torch.float32, device="cuda"),
                           hi=torch.zeros((7, s.cout, 32), **i16), lo=torch.zeros((7, s.cout, 32), **i16))
-        ctx = self.ctx
+        ctx = self.ctxs[self._lane]
         bias = self.params.view(self.params.w_eff, "conv1/bias")
         st = self._stem
         flops = 2.0 * y.rows * 49 * 3 * s.cout
         self._push(Op(lambda: ops.stem7x7s2_fwd3(ctx, B, H, W, Hp, Wp, x4.t, st["hi"], st["lo"], s.cout, bias, True, y.t), "conv_fwd", "conv1",
-                      flops), (x4,), y)
+                      flops, None, self._lane), (x4,), y)
         return y
 
     def _refresh_stem(self):
@@ -846,41 +886,94 @@ class Engine(object):
             ev.record(self.streams[l])
             self.streams[0].wait_event(ev)
 
-    def forward(self, x=None):
-        cur = self._enter()
+    RESIDENT = "resident"  # next_x: the next batch is what x_in holds now (bench.py: the synthetic batch stays in HBM)
+
+    def _load_input(self, inp, lane):
+        """the batch into the stem's input on `lane`'s stream: ("f32", x or None) = NHWC float32 into x_in (pack_rgb follows),
+        ("u8", images, sizes) = the uint8 kernel (mean subtraction + padding + packing in one launch, no pack_rgb)"""
+        if inp[0] == "f32":
+            if inp[1] is not None:
+                with torch.cuda.stream(self.streams[lane]):
+                    self.x_in.copy_(inp[1])
+            return
+        x4 = self.acts["input4"]
+        xd = inp[1]
+        with torch.cuda.stream(self.streams[lane]):  # (temporaries belong to the stream whose kernels use them)
+            if len(inp) > 3 and inp[3] is not None:  # augmentation: warp on the device (utils/image.py:207-214)
+                xd = ops.warp_affine_u8(self.ctxs[lane], xd, inp[3], "linear", inp[4], inp[5])
+            if self.stem3:
+                ops.preprocess_caffe_u8_padded(self.ctxs[lane], xd, inp[2], x4.t, *self.stem_frame)
+            else:
+                ops.preprocess_caffe_u8(self.ctxs[lane], xd, inp[2], x4.t)
+
+    @staticmethod
+    def _input_key(inp):
+        """(kind, the batch tensor itself -- held, so that its identity cannot be recycled -- or RESIDENT)"""
+        return (inp[0], Engine.RESIDENT if inp[1] is None else inp[1])
+
+    @staticmethod
+    def _same_input(a, b):
+        return a is not None and a[0] == b[0] and a[1] is b[1]
+
+    def _run_fwd_ops(self, lo, hi, skip_pack):
         streams = self.streams
-        if x is not None:
-            with torch.cuda.stream(streams[0]):
-                self.x_in.copy_(x)
-        for op in self.fwd_ops:
+        for i in range(lo, hi):
+            op = self.fwd_ops[i]
             st = streams[op.lane]
             for ev in op.waits:
                 st.wait_event(ev)
-            op.fn()
+            if not (skip_pack and i == 0):
+                op.fn()
             if op.done_ev is not None:
                 op.done_ev.record(st)
+
+    def _forward(self, inp, nxt):
+        """inp / nxt: this batch and (optionally) the next one, as _load_input takes them.  With a prefix lane the early prefix
+        of `nxt` is enqueued on the prefix stream as soon as this batch's prefix has been consumed; the next call that
+        brings the same batch finds it done (or running) and starts behind it."""
+        cur = self._enter()
+        lp, ne = self.prefix_lane, self.n_prefix_early
+        assert self.fwd_ops[0].name == "pack_rgb"
+        pre, self._prefetched = self._prefetched, None
+        start = 0
+        if lp is not None and self._same_input(pre, self._input_key(inp)):
+            start = ne  # the early prefix of this batch is already on the prefix stream
+        else:
+            if lp is not None:
+                self._fork([lp])  # (also orders this batch's prefix behind a prefetched one that is not used)
+            self._load_input(inp, lp if lp is not None else 0)
+        trig = self.pf_trigger if (lp is not None and nxt is not None) else ne + 1
+        self._run_fwd_ops(start, trig if lp is not None else len(self.fwd_ops), inp[0] == "u8")
+        if lp is not None:
+            if nxt is not None:
+                # the last prefix launch (lane 0) has read the prefix lane's buffers: the next batch may overwrite them
+                ev = torch.cuda.Event()
+                ev.record(self.streams[0])
+                self.streams[lp].wait_event(ev)
+                nxt = ("f32", None) if nxt[1] is Engine.RESIDENT else nxt
+                self._load_input(nxt, lp)
+                self._run_fwd_ops(0, ne, nxt[0] == "u8")
+                self._prefetched = self._input_key(nxt)
+            self._run_fwd_ops(trig, len(self.fwd_ops), False)
         self._join(list(range(1, self.n_lanes)))
         self._leave(cur)
 
-    def forward_u8(self, images_u8, sizes_hw=None):
+    def forward(self, x=None, next_x=None):
+        """x: NHWC float32 batch (None: what x_in holds).  next_x: the batch of the NEXT call (the same tensor object, unchanged
+        until then; Engine.RESIDENT = x_in as it is) -- its frozen prefix runs beside this batch's trunk."""
+        self._forward(("f32", x), None if next_x is None else ("f32", next_x))
+
+    def forward_u8(self, images_u8, sizes_hw=None, transforms=None, border="replicate", cval=0, next_batch=None):
         """Forward from a uint8 BGR batch [B,H,W,3] on the device: mean subtraction, zero padding and channel packing run
-        in one kernel in place of the host-side preprocess_image / compute_inputs (4x less host->device traffic)."""
-        if sizes_hw is None:
-            sizes_hw = [(self.H, self.W)] * self.B
-        cur = self._enter()
-        x4 = self.acts["input4"]
-        if self.stem3:
-            ops.preprocess_caffe_u8_padded(self.ctx, images_u8, sizes_hw, x4.t, *self.stem_frame)
-        else:
-            ops.preprocess_caffe_u8(self.ctx, images_u8, sizes_hw, x4.t)
-        skip = self.fwd_ops[0]
-        assert skip.name == "pack_rgb"
-        fn, skip.fn = skip.fn, (lambda: None)
-        try:
-            self.forward(None)
-        finally:
-            skip.fn = fn
-        self._leave(cur)
+        in one kernel in place of the host-side preprocess_image / compute_inputs (4x less host->device traffic).
+        transforms: one augmentation matrix per image (the batch is warped on the device first).
+        next_batch: dict(images_u8=, sizes_hw=, transforms=, border=, cval=) of the NEXT call (same tensor object) -> its prefix is prefetched."""
+        full = [(self.H, self.W)] * self.B
+        nxt = None
+        if next_batch is not None:
+            nb = next_batch
+            nxt = ("u8", nb["images_u8"], nb.get("sizes_hw") or full, nb.get("transforms"), nb.get("border", "replicate"), nb.get("cval", 0))
+        self._forward(("u8", images_u8, sizes_hw or full, transforms, border, cval), nxt)
 
     def export_outputs(self):
         """Keras prediction-model outputs (models/retinanet.py:302-335): [boxes3D, cls probs, mask probs]."""
@@ -968,18 +1061,19 @@ class Engine(object):
         self.refresh_planes(only_trainable=True)
         self._leave(cur)
 
-    def train_step(self, x=None, targets=None):
+    def train_step(self, x=None, targets=None, next_x=None):
         """One optimisation step (Keras train_on_batch): fwd + losses + bwd + clipnorm-Adam.  Returns nothing;
-        read `losses()` afterwards (a device->host copy) when the values are wanted."""
+        read `losses()` afterwards (a device->host copy) when the values are wanted.  next_x: see forward()."""
         if targets is not None:
             self.set_targets(*targets)
-        self.forward(x)
+        self.forward(x, next_x)
         self.loss_and_backward()
         if self.grad_sync is not None:
             self.grad_sync.finish()
         self.optimizer_step()
 
-    def train_step_from_annotations(self, images_u8, annotations, image_group=None, transforms=None, border="replicate", cval=0):
+    def train_step_from_annotations(self, images_u8, annotations, image_group=None, transforms=None, border="replicate", cval=0,
+                                    next_batch=None):
         """The lean feed of one optimisation step: a uint8 BGR batch [B,H,W,3] (cuda, or pinned host memory) and the raw
         annotation dicts of preprocessing/generator.py:142-226 (bboxes, labels, poses, segmentations, cam_params, mask,
         mask_ids).  Mean subtraction + packing (image.py:58-60, generator.py:320-336) and target assignment
@@ -987,20 +1081,33 @@ class Engine(object):
         transforms: one 2x3 / 3x3 augmentation matrix per image (utils/transform.py:random_transform): the image is warped on the
         device like apply_transform (utils/image.py:207-214: bilinear, border = TransformParameters.fill_mode: 'replicate' for
         the default 'nearest', or 'constant' with cval) and the id mask like apply_transform2mask; the caller has already
-        moved boxes / poses (generator.py:252-286 does that on the host: a few numbers per object)."""
+        moved boxes / poses (generator.py:252-286 does that on the host: a few numbers per object).
+        next_batch: dict(images_u8=, image_group=, transforms=, border=, cval=) of the NEXT call (the generator's look-ahead; the
+        same images_u8 object must come back): its upload, warp and frozen prefix run beside this step (forward_u8)."""
         from .utils import anchors as UA
         if getattr(self, "_anchors_f64", None) is None:
             self._anchors_f64 = UA.anchors_for_shape_device((self.H, self.W), pyramid_levels=list(arch.PYRAMID_LEVELS[self.pyramid]),
                                                             anchor_params=self.anchor_params)
-        xd = images_u8 if images_u8.is_cuda else images_u8.cuda(non_blocking=True)
-        if transforms is not None:
-            cur = self._enter()
-            xd = ops.warp_affine_u8(self.ctx, xd, transforms, "linear", border, cval)
-            self._leave(cur)
+
+        def sizes(group):
+            return [(self.H, self.W)] * self.B if group is None else [(int(im.shape[0]), int(im.shape[1])) for im in group]
+
+        held, self._next_dev = getattr(self, "_next_dev", None), None
+        if held is not None and held[0] == id(images_u8):
+            xd = held[1]  # uploaded by the previous call's look-ahead
+        else:
+            xd = images_u8 if images_u8.is_cuda else images_u8.cuda(non_blocking=True)
+        nb = None
+        if next_batch is not None and self.prefix_lane is not None:
+            nimg = next_batch["images_u8"]
+            nxd = nimg if nimg.is_cuda else nimg.cuda(non_blocking=True)
+            self._next_dev = (id(nimg), nxd)
+            nb = dict(images_u8=nxd, sizes_hw=sizes(next_batch.get("image_group")), transforms=next_batch.get("transforms"),
+                      border=next_batch.get("border", "replicate"), cval=next_batch.get("cval", 0))
         if image_group is None:
             image_group = [np.empty((self.H, self.W, 3), np.uint8)] * self.B  # only the shapes are read
         self.set_targets(*UA.anchor_targets_bbox_device(self._anchors_f64, image_group, annotations, self.C, mask_transforms=transforms))
-        self.forward_u8(xd, [(int(im.shape[0]), int(im.shape[1])) for im in image_group])
+        self.forward_u8(xd, sizes(image_group), transforms, border, cval, next_batch=nb)
         self.loss_and_backward()
         if self.grad_sync is not None:
             self.grad_sync.finish()

@@ -1,0 +1,122 @@
+"""GPU: the frozen prefix (conv1 + res2, never trained -- bin/train.py / models/resnet.py:87-110 freeze them through their
+BatchNorm layers) of batch i+1 can run on its own stream beside batch i (PP_PREFETCH=1, Engine.forward(next_x=...)).  Software pipelining must
+not change a single bit of the forward pass, whatever the caller does with the look-ahead."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+B, H, W, C = 2, 97, 131, 5
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from pyrapose_amd.runtime import default_context
+    return default_context()
+
+
+def batches(n, seed=0):
+    rng = np.random.default_rng(seed)
+    mean = np.array([103.939, 116.779, 123.68], np.float32)
+    return [torch.from_numpy(rng.integers(0, 256, size=(B, H, W, 3)).astype(np.float32) - mean).cuda() for _ in range(n)]
+
+
+def heads(eng):
+    torch.cuda.synchronize()
+    return [t.clone() for t in (eng.reg_out.t, eng.cls_out.t, eng.mask_out.t)]
+
+
+def same(a, b):
+    return all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def test_prefetched_prefix_is_bit_identical(ctx, monkeypatch):
+    from pyrapose_amd import arch
+    from pyrapose_amd.engine import Engine
+    Wt = arch.init_weights(C, seed=3)
+    xs = batches(4)
+    monkeypatch.delenv("PP_PREFETCH", raising=False)
+    ref = Engine(ctx, C, B, H, W, weights=Wt, train=True)
+    assert ref.prefix_lane is None
+    want = []
+    for x in xs:
+        ref.forward(x)
+        want.append(heads(ref))
+    monkeypatch.setenv("PP_PREFETCH", "1")
+    eng = Engine(ctx, C, B, H, W, weights=Wt, train=True)
+    assert eng.prefix_lane is not None and 0 < eng.n_prefix_early < eng.fwd_fork
+    assert all(op.lane == eng.prefix_lane for op in eng.fwd_ops[: eng.n_prefix_early])
+    assert all(op.lane != eng.prefix_lane for op in eng.fwd_ops[eng.n_prefix_early:])
+    # the prefix on its own stream, no look-ahead
+    eng.forward(xs[0])
+    assert same(heads(eng), want[0])
+    # look-ahead used: batch 1 finds its prefix done, batch 2 likewise
+    eng.forward(xs[0], next_x=xs[1])
+    assert same(heads(eng), want[0])
+    eng.forward(xs[1], next_x=xs[2])
+    assert same(heads(eng), want[1])
+    eng.forward(xs[2])
+    assert same(heads(eng), want[2])
+    # look-ahead announced and NOT honoured: another batch comes, and then the announced one after all
+    eng.forward(xs[0], next_x=xs[1])
+    eng.forward(xs[3])
+    assert same(heads(eng), want[3])
+    eng.forward(xs[1])
+    assert same(heads(eng), want[1])
+    # RESIDENT: the next batch is what x_in holds
+    eng.forward(xs[2], next_x=Engine.RESIDENT)
+    eng.forward(None, next_x=Engine.RESIDENT)
+    assert same(heads(eng), want[2])
+    eng.forward(None)
+    assert same(heads(eng), want[2])
+    ref.close()
+    eng.close()
+
+
+def test_train_steps_with_look_ahead_match(ctx, monkeypatch):
+    """three optimisation steps with and without the look-ahead: same losses (the weight-gradient atomics are the only
+    run-to-run difference, 2e-5), and the frozen prefix is computed once per step either way."""
+    from pyrapose_amd import arch
+    from pyrapose_amd.engine import Engine
+    from tests.test_gpu_model import random_targets
+    Wt = arch.init_weights(C, seed=4)
+    xs = batches(3, seed=1)
+    rng = np.random.default_rng(2)
+    monkeypatch.delenv("PP_PREFETCH", raising=False)
+    a = Engine(ctx, C, B, H, W, weights=Wt, train=True, lr=1e-4)
+    monkeypatch.setenv("PP_PREFETCH", "1")
+    b = Engine(ctx, C, B, H, W, weights=Wt, train=True, lr=1e-4)
+    tg = [tuple(torch.from_numpy(t).cuda() for t in random_targets(rng, B, a.N, a.M3, C)) for _ in range(3)]
+    for i in range(3):
+        a.train_step(xs[i], tg[i])
+        b.train_step(xs[i], tg[i], next_x=xs[i + 1] if i < 2 else None)
+        la, lb = a.losses(), b.losses()
+        for k in la:
+            assert abs(la[k] - lb[k]) <= 2e-5 * max(abs(la[k]), 1e-3), (i, k, la[k], lb[k])
+    wa, wb = a.params.w_master, b.params.w_master
+    assert float((wa - wb).abs().max()) <= 2e-5 * float(wa.abs().max())
+    a.close()
+    b.close()
+
+
+def test_u8_look_ahead_with_augmentation(ctx, monkeypatch):
+    """the lean feed (uint8 batch + per-image affine warp on the device) with the generator's look-ahead"""
+    from pyrapose_amd import arch
+    from pyrapose_amd.engine import Engine
+    rng = np.random.default_rng(7)
+    Wt = arch.init_weights(C, seed=5)
+    monkeypatch.setenv("PP_PREFETCH", "1")
+    eng = Engine(ctx, C, B, H, W, weights=Wt, train=True)
+    assert eng.prefix_lane is not None
+    u8 = [torch.from_numpy(rng.integers(0, 256, size=(B, H, W, 3)).astype(np.uint8)).cuda() for _ in range(3)]
+    tf = [[np.array([[1.05, 0.02, 3.0], [-0.01, 0.97, -2.0], [0, 0, 1.0]]) for _ in range(B)] for _ in range(3)]
+    want = []
+    for i in range(3):
+        eng.forward_u8(u8[i], None, tf[i])
+        want.append(heads(eng))
+    for i in range(3):
+        nb = dict(images_u8=u8[i + 1], transforms=tf[i + 1]) if i < 2 else None
+        eng.forward_u8(u8[i], None, tf[i], next_batch=nb)
+        assert same(heads(eng), want[i]), i
+    eng.close()
