@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
   int n_wg = (int)gridDim.x;
   if (RL) {  // the grid is sized for the dense case: only the first ceil(count / blocks per tile) x n_tiles_n workgroups work,
              // and the XCD remap runs over THEM (over the whole grid the listed tiles would all land on the first XCDs)
-    n_wg = ((g_rl[0] + BM / 32 - 1) / (BM / 32)) * p.n_tiles_n;
+    n_wg = ((g_rl[0] + BM / 32 - 1) / (BM / 32)) * p.n_tiles_n * splits;
     if ((int)blockIdx.x >= n_wg) return;  // workgroup-uniform, before any barrier
   }
   const int lbs = xcd_remap((int)blockIdx.x, n_wg);
@@ -655,16 +655,20 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
   }
   if (splits > 1) {  // partial sums only (slice `split` of the scratch): splitk_finish_kernel sums the slices in a fixed
                      // order and applies the epilogue -> deterministic, no atomics, nothing to zero
-    float* slice = g_ws + (long long)split * p.M * p.ld_out;
+    // (RL: slice rows are COMPACT -- list position * 32 + row in the block, i.e. m0 + tile row -- and every row of a listed
+    // block is written, in range or not: rl_splitk_finish_kernel reads them by list position)
+    float* slice = g_ws + (long long)split * (RL ? (((long long)p.M + 31) & ~31ll) : (long long)p.M) * p.ld_out;
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int trow = wm * 32 * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int m = m0 + trow;
+        const bool row_ok = RL ? (rl_blk[trow >> 5] < p.M) : (m < p.M);
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
           const int co = n0 + wn * 32 * TN + b * 32 + il;
-          if (m < p.M && co < ((p.Nout + 3) & ~3)) slice[(long long)m * p.ld_out + co] = acc[a][b][r];
+          if (row_ok && co < ((p.Nout + 3) & ~3)) slice[(long long)m * p.ld_out + co] = acc[a][b][r];
         }
       }
     return;
@@ -1054,6 +1058,27 @@ __global__ void splitk_finish_kernel(const IgemmParams p, int splits, const floa
   }
 }
 
+// split-K of the row-list launch: block j of the list <-> compact slice rows 32 j .. 32 j + 31
+__global__ void rl_splitk_finish_kernel(const IgemmParams p, int splits, const float* __restrict__ ws, const int* __restrict__ g_rl,
+                                        const float* __restrict__ g_addend, const float* __restrict__ g_mask, float* __restrict__ g_out,
+                                        void* __restrict__ g_ohi, void* __restrict__ g_olo) {
+  const int j = blockIdx.x;
+  if (j >= g_rl[0]) return;
+  const int n4 = (p.Nout + 3) >> 2;
+  const long long slice = (((long long)p.M + 31) & ~31ll) * p.ld_out;
+  const int m0 = g_rl[1 + j] * 32, nr = min(32, p.M - m0);
+  for (int i = threadIdx.x; i < nr * n4; i += blockDim.x) {
+    const int r = i / n4, co = 4 * (i - r * n4);
+    const float* w = ws + ((long long)j * 32 + r) * p.ld_out + co;
+    float4 v = *reinterpret_cast<const float4*>(w);
+    for (int s = 1; s < splits; ++s) {
+      const float4 q = *reinterpret_cast<const float4*>(w + s * slice);
+      v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    finish4(p, v, (long long)(m0 + r), co, true, g_addend, g_mask, g_out, g_ohi, g_olo);
+  }
+}
+
 // ---- activation / gradient split: f32 [rows][ld] -> bf16 hi/lo planes with the same geometry ----
 __global__ void split_planes_kernel(size_t n8, const float4* __restrict__ src, uint4* __restrict__ hi, uint4* __restrict__ lo) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
@@ -1361,25 +1386,40 @@ __global__ void row_block_compact_kernel(const unsigned char* __restrict__ flags
 
 // the whole sparse bwd-data: dilate -> compact -> igemm3f over the listed blocks -> fill the others.  scratch: n_blocks bytes
 // + (n_blocks + 1) ints behind the caller's flags / list (pp_row_block_list documents the sizes).
+// ws / ws_bytes: the split-K scratch (may be NULL).  The listed tiles are few (a fifth of the rows on the bench targets: ~320
+// workgroups of 144 k-steps each on 256 CUs, every one of them alone with its load latencies): with a scratch buffer the
+// reduction is split two ways (PP_SPARSE_DGRAD_SPLITS) and rl_splitk_finish_kernel adds the slices of the listed blocks.
 template <int TM, int TN>
 static void launch_igemm3_rowlist(hipStream_t st, IgemmParams& p, const void* ahi, const void* alo, const void* whi, const void* wlo, int w_rows,
-                                  int w_ld8, void* ohi, void* olo, const unsigned char* dy_flags, unsigned char* out_flags, int* out_list) {
+                                  int w_ld8, void* ohi, void* olo, const unsigned char* dy_flags, unsigned char* out_flags, int* out_list,
+                                  float* ws, size_t ws_bytes) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   const int nb = (p.M + 31) / 32;
+  static const int want_splits = []() { const char* e = getenv("PP_SPARSE_DGRAD_SPLITS"); return e ? atoi(e) : 2; }();
+  const int n_steps = p.kh * p.kw * (p.Cred / 32);
+  int splits = 1;
+  if (ws && want_splits > 1 && (ohi || p.out)) {
+    const long long slice_bytes = (long long)nb * 32 * p.ld_out * 4;
+    splits = want_splits;
+    while (splits > 1 && (n_steps / splits < 24 || slice_bytes * splits > (long long)ws_bytes)) --splits;
+  }
   hipLaunchKernelGGL(rl_dilate_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, p, dy_flags, out_flags, nb);
   hipLaunchKernelGGL(row_block_compact_kernel, dim3(1), dim3(256), 0, st, (const unsigned char*)out_flags, nb, out_list);
   p.n_tiles_n = (p.Nout + BN - 1) / BN;
   const int n_tiles_m = (nb + BM / 32 - 1) / (BM / 32);
   const long long a_bytes = p.src_rows * (long long)p.ld_src * 4, w_bytes = (long long)p.w_taps * w_rows * w_ld8 * 16;
-  const dim3 grid((unsigned)(n_tiles_m * p.n_tiles_n));
+  const dim3 grid((unsigned)(n_tiles_m * p.n_tiles_n * splits));
   if (ahi)  // planes in, planes out (host-checked: both or neither)
     hipLaunchKernelGGL((igemm3f_kernel<TM, TN, true, true, false, true>), grid, dim3(256), 0, st, p, ahi, alo, (unsigned)a_bytes, whi, wlo,
-                       (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)ohi, (uint2*)olo, w_rows, w_ld8, 1, (float*)nullptr,
-                       (const int*)out_list);
+                       (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)ohi, (uint2*)olo, w_rows, w_ld8, splits,
+                       splits > 1 ? ws : (float*)nullptr, (const int*)out_list);
   else
     hipLaunchKernelGGL((igemm3f_kernel<TM, TN, false, false, false, true>), grid, dim3(256), 0, st, p, (const void*)p.src, nullptr,
                        (unsigned)a_bytes, whi, wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)nullptr, (uint2*)nullptr,
-                       w_rows, w_ld8, 1, (float*)nullptr, (const int*)out_list);
+                       w_rows, w_ld8, splits, splits > 1 ? ws : (float*)nullptr, (const int*)out_list);
+  if (splits > 1)
+    hipLaunchKernelGGL(rl_splitk_finish_kernel, dim3((unsigned)nb), dim3(256), 0, st, p, splits, (const float*)ws, (const int*)out_list, p.addend,
+                       p.mask_src, p.out, ohi, olo);
   // In place on the addend (dx == the running sum of the other data gradients of this tensor, no ReLU mask): the rows that no
   // non-zero reaches already hold their value -- nothing to fill (the shared pyramid features' gradient: 103 MB not moved).
   const bool in_place = (ohi != nullptr && p.add_hi == (const void*)ohi && p.ld_add == p.ld_out && !p.out && !p.addend && !p.mask_hi &&
@@ -1749,9 +1789,11 @@ extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d
     unsigned char* out_flags = const_cast<unsigned char*>(skip_flags) + nb;
     int* out_list = const_cast<int*>(skip_list_in) + nb + 1;
     if (rl_mode == 22)
-      launch_igemm3_rowlist<2, 2>(ctx->stream, p, dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8, dx_hi, dx_lo, skip_flags, out_flags, out_list);
+      launch_igemm3_rowlist<2, 2>(ctx->stream, p, dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8, dx_hi, dx_lo, skip_flags, out_flags, out_list, ctx->ws,
+                                  ctx->ws_bytes);
     else
-      launch_igemm3_rowlist<1, 2>(ctx->stream, p, dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8, dx_hi, dx_lo, skip_flags, out_flags, out_list);
+      launch_igemm3_rowlist<1, 2>(ctx->stream, p, dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8, dx_hi, dx_lo, skip_flags, out_flags, out_list, ctx->ws,
+                                  ctx->ws_bytes);
     PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_data_bf16x3");
     return PP_OK;
   }

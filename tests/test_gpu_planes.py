@@ -238,6 +238,56 @@ def test_planes_only_row_block_skip(ctx, frac):
         assert not dw1.any() and not db1.any()
 
 
+@pytest.mark.parametrize("in_place", [False, True])
+def test_row_list_bwd_data_split_k(ctx, in_place):
+    """the listed-block data gradient with a scratch buffer: the reduction is split two ways (few listed tiles, long k-loops)
+    and the slices are added per listed block; same result as the dense launch, with addend + ReLU mask or in place"""
+    from pyrapose_amd import ops
+    rng = np.random.default_rng(23)
+    B, shapes, cin, cout, k = 2, [(20, 26), (10, 13), (5, 7)], 128, 256, 3
+    rows = sum(B * h * w for h, w in shapes)
+    d = ops.make_conv_desc(B, shapes, shapes, cin, cout, k, 1, 1, 1, cin, cout, cout)
+    w = torch.as_tensor(rng.standard_normal((k * k * cin, cout)) * 0.05, dtype=torch.float32).cuda()
+    dy = torch.zeros((rows, cout), dtype=torch.float32, device="cuda")
+    live = torch.as_tensor(rng.uniform(size=rows) < 0.01).cuda()
+    dy[live] = torch.as_tensor(rng.standard_normal((int(live.sum()), cout)), dtype=torch.float32).cuda()
+    i16 = dict(dtype=torch.int16, device="cuda")
+    fh, fl = torch.zeros((k * k, cout, cin), **i16), torch.zeros((k * k, cout, cin), **i16)
+    dh, dl = torch.zeros((k * k, cin, cout), **i16), torch.zeros((k * k, cin, cout), **i16)
+    ops.conv_split_weights3(ctx, d, w, fh, fl, dh, dl)
+    gp = split(ctx, dy)
+    flags, blocks = ops.row_block_list(ctx, dy, cout)
+    nb = (rows + 31) // 32
+    add = torch.as_tensor(rng.standard_normal((rows, cin)), dtype=torch.float32).cuda()
+    msk = None if in_place else torch.relu(torch.as_tensor(rng.standard_normal((rows, cin)), dtype=torch.float32)).cuda()
+    want = torch.full((rows, cin), float("nan"), device="cuda")
+    ops.conv_bwd_data3(ctx, d, dy, dh, dl, add, msk, want)  # dense, float32 operands
+    ap = split(ctx, add)
+    outs = []
+    for ws_mb in (0, 16):
+        ctx.set_workspace(ws_mb << 20)
+        try:
+            if ws_mb:
+                ctx.workspace.fill_(float("nan"))
+            f2, b2 = flags.clone(), blocks.clone()
+            if in_place:
+                acc = split(ctx, add)
+                ops.conv_bwd_data3(ctx, d, None, dh, dl, None, None, None, dy_planes=gp, dx_planes=acc, dy_skip=(f2, b2), addend_planes=acc)
+                got = merged(acc)
+            else:
+                dxp = nan_planes(want)
+                ops.conv_bwd_data3(ctx, d, None, dh, dl, None, None, None, dy_planes=gp, dx_planes=dxp, dy_skip=(f2, b2), addend_planes=ap,
+                                   relu_src_hi=split(ctx, msk)[0])
+                got = merged(dxp)
+            torch.cuda.synchronize()
+            assert 0 < int(f2[nb: 2 * nb].sum()) < nb  # the listed launch ran, and not over everything
+            assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max()), ws_mb
+            outs.append(got)
+        finally:
+            ctx.set_workspace(0)
+    assert float((outs[0] - outs[1]).abs().max()) <= 1e-5 * float(want.abs().max())  # (two partial sums instead of one; planes hold 2^-17)
+
+
 def test_pointwise_ops_on_views(ctx):
     from pyrapose_amd import ops
     rng = np.random.default_rng(5)
