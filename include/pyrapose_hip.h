@@ -153,6 +153,18 @@ typedef struct pp_split_job {
   int tile_begin, reserved;
 } pp_split_job;
 int pp_conv_split_weights_bf16x3_batch(pp_ctx* ctx, int n_jobs, const pp_split_job* jobs_dev, int total_tiles);
+/* Sparse FORWARD of a head whose loss reads a few rows only (training; the 3D-box head: orthogonal_l1 keeps the rows with anchor
+ * state 1, losses.py:332-333 -- every other output row of that head is dead in train_on_batch).
+ * pp_positive_row_blocks: flags[b] = 1 when the 32-row block b of the head's row space holds an anchor whose last target column
+ * (state, column stride - 1 of y_true [n_img][cells][A][stride]) is 1.  pp_row_block_dilate: the blocks within one pixel of a
+ * flagged block (what a 3x3 stride-1 conv d reads to produce the flagged blocks): applied once per layer from the head's output
+ * back to its first conv.  pp_ctx_set_row_block_out is one-shot: the NEXT pp_conv2d_nhwc_fwd_bf16x3 call on this context (3x3,
+ * stride 1, pad 1, plane-stored input, no residual) computes the flagged 32-row output blocks only (compacted four to a tile;
+ * list = scratch of n_blocks + 1 ints) and leaves every other output row as it is.  Exact for the loss, its gradient and the
+ * weight gradients (the backward reads those activations only where its own row-block skip goes); the caller opts in. */
+int pp_positive_row_blocks(pp_ctx* ctx, const pp_rowspace* rs, int A, int stride, const float* y_true, unsigned char* flags);
+int pp_row_block_dilate(pp_ctx* ctx, const pp_conv_desc* d, const unsigned char* in_flags, unsigned char* out_flags);
+int pp_ctx_set_row_block_out(pp_ctx* ctx, const unsigned char* flags, int* list);
 /* f32 tensor of n elements (n % 8 == 0) -> bf16 (hi, lo) planes with the same [rows][ld] geometry.  Convs that are
  * given planes for their gathered operand skip the conversion inside the kernel (the f32 pointer may then be NULL). */
 int pp_split_planes_bf16x3(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo);

@@ -1060,8 +1060,8 @@ __global__ void splitk_finish_kernel(const IgemmParams p, int splits, const floa
 
 // split-K of the row-list launch: block j of the list <-> compact slice rows 32 j .. 32 j + 31
 __global__ void rl_splitk_finish_kernel(const IgemmParams p, int splits, const float* __restrict__ ws, const int* __restrict__ g_rl,
-                                        const float* __restrict__ g_addend, const float* __restrict__ g_mask, float* __restrict__ g_out,
-                                        void* __restrict__ g_ohi, void* __restrict__ g_olo) {
+                                        const float* __restrict__ g_bias, const float* __restrict__ g_addend, const float* __restrict__ g_mask,
+                                        float* __restrict__ g_out, void* __restrict__ g_ohi, void* __restrict__ g_olo) {
   const int j = blockIdx.x;
   if (j >= g_rl[0]) return;
   const int n4 = (p.Nout + 3) >> 2;
@@ -1075,6 +1075,7 @@ __global__ void rl_splitk_finish_kernel(const IgemmParams p, int splits, const f
       const float4 q = *reinterpret_cast<const float4*>(w + s * slice);
       v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
     }
+    if (g_bias) { const float4 b = *reinterpret_cast<const float4*>(g_bias + co); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
     finish4(p, v, (long long)(m0 + r), co, true, g_addend, g_mask, g_out, g_ohi, g_olo);
   }
 }
@@ -1389,10 +1390,12 @@ __global__ void row_block_compact_kernel(const unsigned char* __restrict__ flags
 // ws / ws_bytes: the split-K scratch (may be NULL).  The listed tiles are few (a fifth of the rows on the bench targets: ~320
 // workgroups of 144 k-steps each on 256 CUs, every one of them alone with its load latencies): with a scratch buffer the
 // reduction is split two ways (PP_SPARSE_DGRAD_SPLITS) and rl_splitk_finish_kernel adds the slices of the listed blocks.
+// dy_flags == NULL (forward, pp_ctx_set_row_block_out): out_flags are given -- no dilation, and the rows of the other blocks
+// are left as they are (fill = false).
 template <int TM, int TN>
 static void launch_igemm3_rowlist(hipStream_t st, IgemmParams& p, const void* ahi, const void* alo, const void* whi, const void* wlo, int w_rows,
                                   int w_ld8, void* ohi, void* olo, const unsigned char* dy_flags, unsigned char* out_flags, int* out_list,
-                                  float* ws, size_t ws_bytes) {
+                                  float* ws, size_t ws_bytes, bool fill = true) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   const int nb = (p.M + 31) / 32;
   static const int want_splits = []() { const char* e = getenv("PP_SPARSE_DGRAD_SPLITS"); return e ? atoi(e) : 2; }();
@@ -1403,13 +1406,17 @@ static void launch_igemm3_rowlist(hipStream_t st, IgemmParams& p, const void* ah
     splits = want_splits;
     while (splits > 1 && (n_steps / splits < 24 || slice_bytes * splits > (long long)ws_bytes)) --splits;
   }
-  hipLaunchKernelGGL(rl_dilate_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, p, dy_flags, out_flags, nb);
+  if (dy_flags) hipLaunchKernelGGL(rl_dilate_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, p, dy_flags, out_flags, nb);
   hipLaunchKernelGGL(row_block_compact_kernel, dim3(1), dim3(256), 0, st, (const unsigned char*)out_flags, nb, out_list);
   p.n_tiles_n = (p.Nout + BN - 1) / BN;
   const int n_tiles_m = (nb + BM / 32 - 1) / (BM / 32);
   const long long a_bytes = p.src_rows * (long long)p.ld_src * 4, w_bytes = (long long)p.w_taps * w_rows * w_ld8 * 16;
   const dim3 grid((unsigned)(n_tiles_m * p.n_tiles_n * splits));
-  if (ahi)  // planes in, planes out (host-checked: both or neither)
+  if (ahi && !ohi)  // planes in, float32 out (a head's last conv in the forward pass)
+    hipLaunchKernelGGL((igemm3f_kernel<TM, TN, true, false, false, true>), grid, dim3(256), 0, st, p, ahi, alo, (unsigned)a_bytes, whi, wlo,
+                       (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)nullptr, (uint2*)nullptr, w_rows, w_ld8, splits,
+                       splits > 1 ? ws : (float*)nullptr, (const int*)out_list);
+  else if (ahi)  // planes in, planes out
     hipLaunchKernelGGL((igemm3f_kernel<TM, TN, true, true, false, true>), grid, dim3(256), 0, st, p, ahi, alo, (unsigned)a_bytes, whi, wlo,
                        (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)ohi, (uint2*)olo, w_rows, w_ld8, splits,
                        splits > 1 ? ws : (float*)nullptr, (const int*)out_list);
@@ -1418,14 +1425,14 @@ static void launch_igemm3_rowlist(hipStream_t st, IgemmParams& p, const void* ah
                        (unsigned)a_bytes, whi, wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)nullptr, (uint2*)nullptr,
                        w_rows, w_ld8, splits, splits > 1 ? ws : (float*)nullptr, (const int*)out_list);
   if (splits > 1)
-    hipLaunchKernelGGL(rl_splitk_finish_kernel, dim3((unsigned)nb), dim3(256), 0, st, p, splits, (const float*)ws, (const int*)out_list, p.addend,
-                       p.mask_src, p.out, ohi, olo);
+    hipLaunchKernelGGL(rl_splitk_finish_kernel, dim3((unsigned)nb), dim3(256), 0, st, p, splits, (const float*)ws, (const int*)out_list, p.bias,
+                       p.addend, p.mask_src, p.out, ohi, olo);
   // In place on the addend (dx == the running sum of the other data gradients of this tensor, no ReLU mask): the rows that no
   // non-zero reaches already hold their value -- nothing to fill (the shared pyramid features' gradient: 103 MB not moved).
   const bool in_place = (ohi != nullptr && p.add_hi == (const void*)ohi && p.ld_add == p.ld_out && !p.out && !p.addend && !p.mask_hi &&
                          !p.mask_src && !p.relu) ||
                         (p.out != nullptr && p.addend == p.out && p.ld_add == p.ld_out && !ohi && !p.add_hi && !p.mask_hi && !p.mask_src && !p.relu);
-  if (!in_place)
+  if (fill && !in_place)
     hipLaunchKernelGGL(rl_fill_kernel, dim3((unsigned)nb), dim3(256), 0, st, p, (const unsigned char*)out_flags, p.addend, p.mask_src, p.out, ohi,
                        olo);
 }
@@ -1606,6 +1613,10 @@ extern "C" int pp_conv2d_nhwc_fwd_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, con
   ctx->cap_hi = ctx->cap_lo = nullptr;
   const void *ep_ah = ctx->ep_add_hi, *ep_al = ctx->ep_add_lo;  // one-shot (pp_ctx_set_epilogue_planes): the residual as planes
   ctx->ep_add_hi = ctx->ep_add_lo = ctx->ep_mask_hi = nullptr;
+  const unsigned char* out_flags = ctx->out_flags;  // one-shot (pp_ctx_set_row_block_out)
+  int* out_list = ctx->out_list;
+  ctx->out_flags = nullptr;
+  ctx->out_list = nullptr;
   int rc = check_desc(ctx, d, "pp_conv2d_nhwc_fwd_bf16x3");
   PP_CHECK_ARG(ctx, !(ep_ah && residual), PP_ERR_ARG, "pp_conv2d_nhwc_fwd_bf16x3: residual given both as f32 and as planes");
   PP_CHECK_ARG(ctx, !ep_ah || (ld_res % 4 == 0 && ld_res >= ((d->cout + 3) & ~3)), PP_ERR_SHAPE, "pp_conv2d_nhwc_fwd_bf16x3: residual planes");
@@ -1637,8 +1648,41 @@ extern "C" int pp_conv2d_nhwc_fwd_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, con
   p.w_ty0 = 0; p.w_tx0 = 0; p.w_tstep = 1; p.w_kw = d->kw; p.w_taps = d->kh * d->kw;
   PP_CHECK_ARG(ctx, (y_hi == nullptr) == (y_lo == nullptr) && (!y_hi || (d->ld_y % 4 == 0 && pp_is_aligned16(y_hi) && pp_is_aligned16(y_lo))),
                PP_ERR_ARG, "pp_conv2d_nhwc_fwd_bf16x3: output planes");
+  if (out_flags) {
+    // only the flagged 32-row output blocks (the listed-block launch of the sparse data gradient, without dilation and fill):
+    // plane-stored input, 3x3 stride 1 pad 1 on an unchanged grid, no residual
+    bool ok = x_hi != nullptr && ((y != nullptr) != (y_hi != nullptr)) && !chi && !residual && !ep_ah && d->stride == 1 && d->kh == 3 && d->kw == 3 && d->pad_t == 1 &&
+              d->pad_l == 1 && igemm3_fast_ok(p, true, d->cout, d->cin / 8);
+    for (int i = 0; i < p.n_seg && ok; ++i)
+      ok = p.seg[i].OH == p.seg[i].SH && p.seg[i].OW == p.seg[i].SW && p.seg[i].row_begin == p.seg[i].src_row_begin;
+    PP_CHECK_ARG(ctx, ok, PP_ERR_SHAPE, "pp_conv2d_nhwc_fwd_bf16x3: the row-block-out hint needs a 3x3 stride-1 'same' conv on plane-stored input");
+    launch_igemm3_rowlist<2, 2>(ctx->stream, p, x_hi, x_lo, w_hi, w_lo, d->cout, d->cin / 8, y_hi, y_lo, nullptr, const_cast<unsigned char*>(out_flags),
+                                out_list, ctx->ws, ctx->ws_bytes, false);
+    PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_fwd_bf16x3");
+    return PP_OK;
+  }
   dispatch3(ctx, p, x_hi, x_lo, w_hi, w_lo, d->cout, d->cin / 8, y_hi, y_lo, chi, clo);
   PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_fwd_bf16x3");
+  return PP_OK;
+}
+
+// out_flags[b] = 1 when a flagged block of in_flags lies within one pixel (2-D, 32-row granularity) of block b of the row
+// space of a 3x3 stride-1 'same' conv d (the blocks of its input that the flagged blocks of its output read, and vice versa)
+extern "C" int pp_row_block_dilate(pp_ctx* ctx, const pp_conv_desc* d, const unsigned char* in_flags, unsigned char* out_flags) {
+  PP_REQUIRE_CTX(ctx);
+  int rc = check_desc(ctx, d, "pp_row_block_dilate");
+  if (rc) return rc;
+  PP_CHECK_ARG(ctx, in_flags && out_flags && in_flags != out_flags, PP_ERR_ARG, "pp_row_block_dilate: two distinct flag buffers");
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.n_seg = d->in.n_seg;
+  fill_segs(ctx, d, true, p.seg, &p.M, &p.src_rows);
+  bool same = d->stride == 1 && d->kh == 3 && d->kw == 3;
+  for (int i = 0; i < p.n_seg && same; ++i) same = p.seg[i].OH == p.seg[i].SH && p.seg[i].OW == p.seg[i].SW && p.seg[i].row_begin == p.seg[i].src_row_begin;
+  PP_CHECK_ARG(ctx, same, PP_ERR_SHAPE, "pp_row_block_dilate: 3x3 stride-1 conv on an unchanged grid");
+  const int nb = (p.M + 31) / 32;
+  hipLaunchKernelGGL(rl_dilate_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, ctx->stream, p, in_flags, out_flags, nb);
+  PP_CHECK_LAUNCH(ctx, "pp_row_block_dilate");
   return PP_OK;
 }
 

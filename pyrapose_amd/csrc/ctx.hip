@@ -72,6 +72,14 @@ extern "C" int pp_ctx_set_row_block_skip(pp_ctx* ctx, const unsigned char* flags
   return PP_OK;
 }
 
+extern "C" int pp_ctx_set_row_block_out(pp_ctx* ctx, const unsigned char* flags, int* list) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, (flags == nullptr) == (list == nullptr), PP_ERR_ARG, "pp_ctx_set_row_block_out: flags and list go together");
+  ctx->out_flags = flags;
+  ctx->out_list = list;
+  return PP_OK;
+}
+
 extern "C" const char* pp_last_error_string(pp_ctx* ctx) { return ctx ? ctx->err : "no context"; }
 
 extern "C" int pp_device_info(pp_ctx* ctx, int* n_cu, char* name, int name_len) {

@@ -74,6 +74,37 @@ extern "C" int pp_count_positives(pp_ctx* ctx, size_t rows_box, const float* y_b
   return PP_OK;
 }
 
+// ---- which 32-row blocks of a head's row space hold an anchor with state 1? (pp_positive_row_blocks) ----
+__global__ void positive_blocks_kernel(HeadGeo g, int A, int stride, const float* __restrict__ y_true, unsigned char* __restrict__ flags) {
+  const size_t total = (size_t)g.n_img * g.cells_total * A;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    if (y_true[i * stride + (stride - 1)] != 1.0f) continue;
+    size_t t = i / A;
+    const int cell = (int)(t % g.cells_total);
+    const int b = (int)(t / g.cells_total);
+    int s = 0;
+    for (int k = 1; k < g.n_seg; ++k)
+      if (cell >= g.cell_off[k]) s = k;
+    const int m = g.row_begin[s] + b * g.hw[s] + (cell - g.cell_off[s]);
+    flags[m >> 5] = 1;
+  }
+}
+
+extern "C" int pp_positive_row_blocks(pp_ctx* ctx, const pp_rowspace* rs, int A, int stride, const float* y_true, unsigned char* flags) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, rs && y_true && flags && A > 0 && stride > 1 && rs->n_seg >= 1 && rs->n_seg <= PP_MAX_SEG, PP_ERR_ARG, "pp_positive_row_blocks: bad arguments");
+  HeadGeo g;
+  fill_head_geo(rs, &g);
+  const size_t nb = ((size_t)g.row_begin[g.n_seg] + 31) / 32;
+  PP_HIP(ctx, hipMemsetAsync(flags, 0, nb, ctx->stream));
+  const size_t total = (size_t)g.n_img * g.cells_total * A;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(positive_blocks_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g, A, stride, y_true, flags);
+  PP_CHECK_LAUNCH(ctx, "pp_positive_row_blocks");
+  return PP_OK;
+}
+
 // ---- sigmoid focal loss ---------------------------------------------------------------------------
 // One thread per (row m, padded channel ch).  ch = a*C + c.
 __global__ void focal_kernel(HeadGeo g, int A, int C, const float* __restrict__ logits, int ld, const float* __restrict__ y_true,

@@ -22,6 +22,8 @@ struct pp_ctx {
   const void* ep_mask_hi;
   const int* skip_list;              // one-shot: row-block skip of the next bf16x3 bwd-weight (list) / bwd-data (flags) call
   const unsigned char* skip_flags;
+  const unsigned char* out_flags;    // one-shot: the next bf16x3 forward call computes the flagged 32-row output blocks only
+  int* out_list;                     //           (pp_ctx_set_row_block_out; list = its scratch)
 };
 
 static inline int pp_fail(pp_ctx* ctx, int code, const char* fmt, ...) {

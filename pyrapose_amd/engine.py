@@ -271,6 +271,8 @@ class Engine(object):
         # output tiles that cannot see one.  Exact: a zero row adds 0.0 to every sum.
         self.sparse_bwd = tuple(t for t in _os.environ.get("PP_SPARSE_BWD", "reg").split(",") if t and t != "0") \
             if self.conv_mode == "bf16x3" else ()
+        # opt-in: the FORWARD of that head on the same blocks in training steps (_plan_sparse_forward)
+        self.sparse_fwd = (self.train and self.po and "reg" in self.sparse_bwd and _os.environ.get("PP_SPARSE_FWD", "0") == "1")
         self.capture_min_cin = int(_os.environ.get("PP_CAPTURE_MIN_CIN", "64"))
         self.capture_skip = tuple(t for t in _os.environ.get("PP_CAPTURE_SKIP", "").split(",") if t)
         self.planes = OrderedDict()  # spec name -> dict(desc, fwd_hi, fwd_lo, dg_hi, dg_lo)
@@ -549,7 +551,8 @@ class Engine(object):
         self.cls_out = run_head("cls", pyr)
         # the mask head (P3 only: 0.6 ms) follows the class head on lane 1 when there are two lanes: the 3D-box head (2.3 ms)
         # has lane 0 to itself and both lanes stay busy for longer (PP_MASK_LANE overrides)
-        self._lane = int(_os.environ.get("PP_MASK_LANE", "1" if self.n_lanes == 2 else "2")) % self.n_lanes
+        # (with the sparse forward of the 3D-box head lane 0 is the short one: the mask head goes there)
+        self._lane = int(_os.environ.get("PP_MASK_LANE", ("0" if self.sparse_fwd else "1") if self.n_lanes == 2 else "2")) % self.n_lanes
         self.mask_out = run_head("mask", P3)
         self._lane = 0
         # interleave the three chains in enqueue order so that every lane has work from the start
@@ -564,12 +567,47 @@ class Engine(object):
         self._link_lanes()
         # where in the forward plan the next batch's prefix is released (after the launch of that name; default: as soon as this
         # batch's own prefix has been consumed)
+        if self.sparse_fwd:
+            self._plan_sparse_forward()
         self.pf_trigger = self.n_prefix_early + 1
         after = _os.environ.get("PP_PREFETCH_AFTER")
         if after and self.prefix_lane is not None:
             idx = [i for i, o in enumerate(self.fwd_ops) if o.name == after and o.lane == 0]
             assert idx, "PP_PREFETCH_AFTER=%s: no such lane-0 launch" % after
             self.pf_trigger = max(self.pf_trigger, idx[0] + 1)
+
+    def _plan_sparse_forward(self):
+        """Sparse forward of the 3D-box head in a TRAINING step (opt-in, PP_SPARSE_FWD=1): orthogonal_l1 reads that head's output
+        at the anchors with state 1 only (losses.py:332-333), so the step needs reg_out on the 32-row blocks that hold a positive
+        anchor, reg_conv3 on those within one pixel of them, ... reg_conv0 within four -- the same block sets the sparse
+        backward finds in the gradient.  Per step: one scan of the targets + four dilations (train_step), then every conv of
+        the head runs the listed-block launch (pp_ctx_set_row_block_out).  The other rows of the head's tensors keep stale values
+        that nothing reads: the loss masks them, the backward's row-block skip never goes there.  forward() / predict paths
+        are not affected (the hint is set inside train_step only)."""
+        names = ["reg_conv0", "reg_conv1", "reg_conv2", "reg_conv3", "reg_out"]
+        nb = (self.pyr.rows + 31) // 32
+        dev = dict(device="cuda")
+        self._sf_flags = [torch.zeros((nb,), dtype=torch.uint8, **dev) for _ in names]
+        self._sf_lists = [torch.zeros((nb + 1,), dtype=torch.int32, **dev) for _ in names]
+        self._sf_desc = next(g["desc"] for g in self.graph_ops if g.get("kind") == "conv" and g["spec"].name == "reg_conv1")
+        self._sparse_fwd_now = False
+        by_name = {o.name: o for o in self.fwd_ops}
+        for k, name in enumerate(names):
+            op = by_name[name]
+            octx = self.ctxs[op.lane]
+
+            def fn(inner=op.fn, k=k, octx=octx):
+                if self._sparse_fwd_now:
+                    ops.set_row_block_out(octx, self._sf_flags[k], self._sf_lists[k])
+                inner()
+            op.fn = fn
+
+    def _sparse_forward_lists(self):
+        """the block sets of this step's targets (lane 0; ~25 us)"""
+        F = self._sf_flags
+        ops.positive_row_blocks(self.ctx, self.pyr.rowspace(), self.A, self.y_box, F[4])
+        for k in (3, 2, 1, 0):
+            ops.row_block_dilate(self.ctx, self._sf_desc, F[k + 1], F[k])
 
     def _build_stem3(self, x4):
         B, H, W = self.B, self.H, self.W
@@ -1066,11 +1104,24 @@ class Engine(object):
         read `losses()` afterwards (a device->host copy) when the values are wanted.  next_x: see forward()."""
         if targets is not None:
             self.set_targets(*targets)
-        self.forward(x, next_x)
+        self._train_forward(lambda: self.forward(x, next_x))
         self.loss_and_backward()
         if self.grad_sync is not None:
             self.grad_sync.finish()
         self.optimizer_step()
+
+    def _train_forward(self, run_forward):
+        """the forward pass of a training step: with PP_SPARSE_FWD=1 the 3D-box head computes the blocks its loss reads only"""
+        if not self.sparse_fwd:
+            return run_forward()
+        cur = self._enter()
+        self._sparse_forward_lists()
+        self._leave(cur)
+        self._sparse_fwd_now = True
+        try:
+            run_forward()
+        finally:
+            self._sparse_fwd_now = False
 
     def train_step_from_annotations(self, images_u8, annotations, image_group=None, transforms=None, border="replicate", cval=0,
                                     next_batch=None):
@@ -1107,7 +1158,7 @@ class Engine(object):
         if image_group is None:
             image_group = [np.empty((self.H, self.W, 3), np.uint8)] * self.B  # only the shapes are read
         self.set_targets(*UA.anchor_targets_bbox_device(self._anchors_f64, image_group, annotations, self.C, mask_transforms=transforms))
-        self.forward_u8(xd, sizes(image_group), transforms, border, cval, next_batch=nb)
+        self._train_forward(lambda: self.forward_u8(xd, sizes(image_group), transforms, border, cval, next_batch=nb))
         self.loss_and_backward()
         if self.grad_sync is not None:
             self.grad_sync.finish()

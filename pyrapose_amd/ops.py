@@ -217,6 +217,25 @@ def merge_planes3(ctx, planes, dst):
     check(lib.pp_merge_planes_bf16x3(ctx.handle, dst.numel(), _ptr(planes[0]), _ptr(planes[1]), _ptr(dst)), ctx.handle, "pp_merge_planes_bf16x3")
 
 
+def positive_row_blocks(ctx, rs, n_anchor, y_true, flags):
+    """pp_positive_row_blocks: flags[b] = 1 where the 32-row block b of the row space rs holds an anchor with state 1
+    (y_true [B, N, stride], state = last column)"""
+    check(lib.pp_positive_row_blocks(ctx.handle, C.byref(rs), int(n_anchor), int(y_true.shape[-1]), _ptr(y_true), _ptr(flags)), ctx.handle,
+          "pp_positive_row_blocks")
+    return flags
+
+
+def row_block_dilate(ctx, d, in_flags, out_flags):
+    """pp_row_block_dilate: the blocks within one pixel (2-D) of a flagged block, on the grid of the 3x3 stride-1 conv d"""
+    check(lib.pp_row_block_dilate(ctx.handle, C.byref(d), _ptr(in_flags), _ptr(out_flags)), ctx.handle, "pp_row_block_dilate")
+    return out_flags
+
+
+def set_row_block_out(ctx, flags, blocks):
+    """pp_ctx_set_row_block_out (one-shot): the next conv_fwd3 on ctx computes the flagged 32-row output blocks only"""
+    check(lib.pp_ctx_set_row_block_out(ctx.handle, _ptr(flags), _ptr(blocks)), ctx.handle, "pp_ctx_set_row_block_out")
+
+
 def _set_skip(ctx, skip):
     if skip is not None:
         check(lib.pp_ctx_set_row_block_skip(ctx.handle, _ptr(skip[0]), _ptr(skip[1])), ctx.handle, "pp_ctx_set_row_block_skip")

@@ -120,3 +120,52 @@ def test_u8_look_ahead_with_augmentation(ctx, monkeypatch):
         eng.forward_u8(u8[i], None, tf[i], next_batch=nb)
         assert same(heads(eng), want[i]), i
     eng.close()
+
+
+def test_sparse_forward_of_box_head_is_exact_for_training(ctx, monkeypatch):
+    """PP_SPARSE_FWD=1: in a training step the 3D-box head computes only the 32-row blocks its loss reads (anchors with state 1,
+    losses.py:332-333) and what those need, layer by layer.  Losses, gradients and updated weights equal the dense forward's
+    (different kernel for the listed blocks: f32 summation order), step after step with new targets; forward() outside a
+    training step still computes every row."""
+    from pyrapose_amd import arch
+    from pyrapose_amd.engine import Engine
+    from tests.test_gpu_model import random_targets
+    Bq, Hq, Wq, Cq = 2, 160, 224, 5
+    Wt = arch.init_weights(Cq, seed=6)
+    rng = np.random.default_rng(3)
+    mean = np.array([103.939, 116.779, 123.68], np.float32)
+    xs = [torch.from_numpy(rng.integers(0, 256, size=(Bq, Hq, Wq, 3)).astype(np.float32) - mean).cuda() for _ in range(3)]
+    # (lr = 0 for the first three steps: both engines keep identical weights, so that their gradients can be compared at kernel
+    # precision step after step -- with new inputs and targets each time, i.e. with stale rows of the step before lying around;
+    # a fourth step with lr > 0 compares the updated weights)
+    monkeypatch.delenv("PP_SPARSE_FWD", raising=False)
+    a = Engine(ctx, Cq, Bq, Hq, Wq, weights=Wt, train=True, lr=0.0)
+    monkeypatch.setenv("PP_SPARSE_FWD", "1")
+    b = Engine(ctx, Cq, Bq, Hq, Wq, weights=Wt, train=True, lr=0.0)
+    assert b.sparse_fwd and not a.sparse_fwd
+    for i in range(4):
+        if i == 3:
+            a.lr = b.lr = 1e-4
+        tg = [torch.from_numpy(t).cuda() for t in random_targets(rng, Bq, a.N, a.M3, Cq, pos_frac=0.0005)]
+        a.train_step(xs[i % 3], tg)
+        b.train_step(xs[i % 3], tg)
+        torch.cuda.synchronize()
+        nb = b._sf_flags[4].numel()
+        assert 0 < int(b._sf_flags[4].sum()) <= int(b._sf_flags[0].sum()) < nb  # some blocks, more of them layer by layer, not all
+        la, lb = a.losses(), b.losses()
+        for k in la:
+            assert abs(la[k] - lb[k]) <= 2e-5 * max(abs(la[k]), 1e-3), (i, k, la[k], lb[k])
+        ga, gb = a.params.grad, b.params.grad
+        # (the listed-block launch sums in another order than the dense kernel: ~1e-6 per activation, and a ReLU input of the head
+        # that is zero to rounding may flip -- 1e-4 of the gradient's scale has been seen; a stale row would show as O(1))
+        assert float((ga - gb).abs().max()) <= 5e-4 * float(ga.abs().max()), i
+    wa, wb = a.params.w_master, b.params.w_master
+    assert float((wa - wb).abs().max()) <= 5e-5 * float(wa.abs().max())
+    # outside a training step nothing is skipped
+    a.forward(xs[0])
+    b.forward(xs[0])
+    torch.cuda.synchronize()
+    ra, rb = a.reg_out.t[:, : a.reg_out.C], b.reg_out.t[:, : b.reg_out.C]
+    assert float((ra - rb).abs().max()) <= 2e-5 * float(ra.abs().max())
+    a.close()
+    b.close()
