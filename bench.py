@@ -548,7 +548,7 @@ def main_worker(args):
             if mode == "bf16x3" and os.environ.get("PP_SPARSE_FWD", "0") != "1":
                 # NOT part of `value`: the opt-in PP_SPARSE_FWD=1 also skips, in the FORWARD pass of a training step, the rows of the
                 # 3D-box head that its loss never reads (dead outputs in train_on_batch; losses / gradients / weights unchanged,
-                # tests/test_gpu_prefetch.py) -- reported so that the number exists, kept out of the headline because the skipped
+                # tests/test_gpu_pipeline.py) -- reported so that the number exists, kept out of the headline because the skipped
                 # rows are not zeros but unread values
                 dt4, img4, losses4, _, _ = run(mode, max(3, args.steps // 2), 2, False, sparse_fwd=True)
                 sparse["sparse_forward_opt_in"] = {"value": img4 / dt4, "unit": "images/sec", "ms_per_step": 1e3 * dt4 / max(3, args.steps // 2),

@@ -301,7 +301,7 @@ class Engine(object):
         # its trunk / heads (forward(next_x=...): software pipelining over steps; the trunk's launches are small and leave
         # most of the chip idle, the prefix is HBM-bound).  Its launches get a stream and a native context of their own; all but the LAST of them (res2c_branch2c, which writes the tensor that res3a's weight
         # gradients read until the end of the step) only touch buffers that nothing else reads.  Opt-in (PP_PREFETCH=1): bit-identical
-        # results (tests/test_gpu_prefetch.py), but the bench step gains only 0.5-1 % -- the HBM-bound prefix raises the memory latency
+        # results (tests/test_gpu_pipeline.py), but the bench step gains only 0.5-1 % -- the HBM-bound prefix raises the memory latency
         # that the trunk's small launches are bound by, and released later (beside the heads or the backward: PP_PREFETCH_AFTER) it
         # gains nothing.  Default: the prefix is part of lane 0.
         self.prefix_lane = None

@@ -1,6 +1,8 @@
-"""GPU: the frozen prefix (conv1 + res2, never trained -- bin/train.py / models/resnet.py:87-110 freeze them through their
-BatchNorm layers) of batch i+1 can run on its own stream beside batch i (PP_PREFETCH=1, Engine.forward(next_x=...)).  Software pipelining must
-not change a single bit of the forward pass, whatever the caller does with the look-ahead."""
+"""GPU: two optional restructurings of the training step that must not change its results.
+(1) Look-ahead (PP_PREFETCH=1): the frozen prefix (conv1 + res2, never trained -- bin/train.py / models/resnet.py:87-110 freeze
+them through their BatchNorm layers) of batch i+1 runs on its own stream beside batch i (Engine.forward(next_x=...)): not a
+single bit of the forward pass may change, whatever the caller does with the look-ahead.
+(2) Sparse forward of the 3D-box head (PP_SPARSE_FWD=1): in a training step that head computes only what its loss reads."""
 import numpy as np
 import pytest
 import torch
@@ -169,3 +171,53 @@ def test_sparse_forward_of_box_head_is_exact_for_training(ctx, monkeypatch):
     assert float((ra - rb).abs().max()) <= 2e-5 * float(ra.abs().max())
     a.close()
     b.close()
+
+
+def test_positive_row_blocks_and_dilation_match_numpy(ctx):
+    """pp_positive_row_blocks / pp_row_block_dilate against a plain restatement: block b is flagged when one of its 32 rows holds
+    an anchor with state 1; the dilation flags b when a flagged block meets one of the three 34-row windows
+    [32 b - 1 + j W, 32 b + 32 + j W], j = -1, 0, 1, W = width of the level block b lies in (conv3.hip: rl_dilate_kernel)."""
+    from pyrapose_amd import ops
+    rng = np.random.default_rng(9)
+    Bq, shapes, A = 2, [(20, 26), (10, 13), (5, 7)], 9
+    rs = ops.RowSpace.make(Bq, shapes)
+    cells = sum(h * w for h, w in shapes)
+    rows = Bq * cells
+    y = rng.standard_normal((Bq, cells * A, 17)).astype(np.float32)
+    state = np.where(rng.uniform(size=(Bq, cells * A)) < 0.002, 1.0, np.where(rng.uniform(size=(Bq, cells * A)) < 0.05, -1.0, 0.0))
+    y[:, :, 16] = state
+    nb = (rows + 31) // 32
+    flags = torch.full((nb,), 7, dtype=torch.uint8, device="cuda")
+    ops.positive_row_blocks(ctx, rs, A, torch.from_numpy(y).cuda(), flags)
+    # row of (image b, cell c of level s) = row_begin[s] + b * hw[s] + (c - cell_off[s])  (the layout of every head tensor)
+    want = np.zeros(nb, np.uint8)
+    row_begin, cell_off, seg_of_row, rb, co = [], [], np.zeros(rows, np.int64), 0, 0
+    for s, (h, w) in enumerate(shapes):
+        row_begin.append(rb); cell_off.append(co)
+        seg_of_row[rb: rb + Bq * h * w] = s
+        rb += Bq * h * w; co += h * w
+    for b in range(Bq):
+        for i in np.nonzero(state[b] == 1.0)[0]:
+            c = i // A
+            s = max(k for k in range(len(shapes)) if c >= cell_off[k])
+            m = row_begin[s] + b * shapes[s][0] * shapes[s][1] + (c - cell_off[s])
+            want[m >> 5] = 1
+    assert want.any() and not want.all()
+    assert np.array_equal(flags.cpu().numpy(), want)
+    d = ops.make_conv_desc(Bq, shapes, shapes, 64, 64, 3, 1, 1, 1, 64, 64, 64)
+    out = torch.full((nb,), 7, dtype=torch.uint8, device="cuda")
+    ops.row_block_dilate(ctx, d, flags, out)
+    want2 = np.zeros(nb, np.uint8)
+    for bq in range(nb):
+        r_lo, r_hi = 32 * bq, min(32 * bq + 31, rows - 1)
+        hit = False
+        for s, (h, w) in enumerate(shapes):
+            seg_lo, seg_hi = row_begin[s], (row_begin[s + 1] if s + 1 < len(shapes) else rows) - 1
+            if r_hi < seg_lo or r_lo > seg_hi:
+                continue
+            for j in (-1, 0, 1):
+                lo, hi = max(r_lo - 1 + j * w, 0), min(r_hi + 1 + j * w, rows - 1)
+                hit = hit or bool(want[lo >> 5: (hi >> 5) + 1].any())
+        want2[bq] = 1 if hit else 0
+    assert np.array_equal(out.cpu().numpy(), want2)
+    assert (want2 >= want).all() and want2.sum() > want.sum()
