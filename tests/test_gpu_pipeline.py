@@ -162,7 +162,9 @@ def test_sparse_forward_of_box_head_is_exact_for_training(ctx, monkeypatch):
         # that is zero to rounding may flip -- 1e-4 of the gradient's scale has been seen; a stale row would show as O(1))
         assert float((ga - gb).abs().max()) <= 5e-4 * float(ga.abs().max()), i
     wa, wb = a.params.w_master, b.params.w_master
-    assert float((wa - wb).abs().max()) <= 5e-5 * float(wa.abs().max())
+    # (one Adam step moves every weight by ~lr whatever the size of its gradient: where the two gradients are noise of opposite
+    # sign the weights part by 2 lr -- that, not a relative bound, is the scale of an honest difference)
+    assert float((wa - wb).abs().max()) <= 2.5 * 1e-4
     # outside a training step nothing is skipped
     a.forward(xs[0])
     b.forward(xs[0])
