@@ -161,6 +161,18 @@ def test_sparse_forward_of_box_head_is_exact_for_training(ctx, monkeypatch):
         # (the listed-block launch sums in another order than the dense kernel: ~1e-6 per activation, and a ReLU input of the head
         # that is zero to rounding may flip -- 1e-4 of the gradient's scale has been seen; a stale row would show as O(1))
         assert float((ga - gb).abs().max()) <= 5e-4 * float(ga.abs().max()), i
+    # a batch without a single positive anchor: nothing of the head is computed, its loss and gradient are zero in both engines
+    a.lr = b.lr = 0.0
+    tg = [torch.from_numpy(t).cuda() for t in random_targets(rng, Bq, a.N, a.M3, Cq, pos_frac=0.0)]
+    a.train_step(xs[1], tg)
+    b.train_step(xs[1], tg)
+    torch.cuda.synchronize()
+    assert int(b._sf_flags[0].sum()) == 0
+    la, lb = a.losses(), b.losses()
+    assert la["3Dbox"] == 0.0 and lb["3Dbox"] == 0.0
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 2e-5 * max(abs(la[k]), 1e-3), (k, la[k], lb[k])
+    assert float((a.params.grad - b.params.grad).abs().max()) <= 5e-4 * float(a.params.grad.abs().max())
     wa, wb = a.params.w_master, b.params.w_master
     # (one Adam step moves every weight by ~lr whatever the size of its gradient: where the two gradients are noise of opposite
     # sign the weights part by 2 lr -- that, not a relative bound, is the scale of an honest difference)
