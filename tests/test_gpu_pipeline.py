@@ -172,7 +172,9 @@ def test_sparse_forward_of_box_head_is_exact_for_training(ctx, monkeypatch):
     assert la["3Dbox"] == 0.0 and lb["3Dbox"] == 0.0
     for k in la:
         assert abs(la[k] - lb[k]) <= 2e-5 * max(abs(la[k]), 1e-3), (k, la[k], lb[k])
-    assert float((a.params.grad - b.params.grad).abs().max()) <= 5e-4 * float(a.params.grad.abs().max())
+    # (without the box loss the largest gradient is ~7e-3 while the float32 atomics of the weight gradients still scatter ~4e-6:
+    # an absolute floor beside the relative bound)
+    assert float((a.params.grad - b.params.grad).abs().max()) <= 5e-4 * float(a.params.grad.abs().max()) + 2e-5
     wa, wb = a.params.w_master, b.params.w_master
     # (one Adam step moves every weight by ~lr whatever the size of its gradient: where the two gradients are noise of opposite
     # sign the weights part by 2 lr -- that, not a relative bound, is the scale of an honest difference)
