@@ -190,18 +190,32 @@ def _free_port():
     return port
 
 
-def spawn_ranks(n, argv, worker=None, timeout=None, env_extra=None):
+DEFAULT_RANK_TIMEOUT_S = 900.0
+
+
+def _tail(f, n=40):
+    f.flush()
+    f.seek(0)
+    lines = f.read().splitlines()
+    return lines[-n:]
+
+
+def spawn_ranks(n, argv, worker=None, timeout=DEFAULT_RANK_TIMEOUT_S, env_extra=None):
     """`bench.py --gpus N` started WITHOUT a launcher (WORLD_SIZE unset): start the N ranks ourselves.
 
     This process has made no GPU call (torch is not even imported) and makes none: it starts one child per rank --
     `python bench.py <same argv>` with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in the
     environment, which is exactly what torch.distributed.run would export -- waits for them, relays rank 0's JSON line
-    and returns non-zero if any rank failed (the others are then terminated by PID; nothing is ever re-exec'd).
-    `worker` (tests): the argv prefix to run instead of [python, bench.py]."""
+    and returns non-zero if any rank failed (the others are then terminated by PID; nothing is ever re-exec'd, a failed rank
+    is never restarted in place).  `timeout` (seconds, `--rank-timeout`, default 900; None / 0 = none): a rank stuck in RCCL
+    initialisation ends the run with a message instead of hanging the parent.  Every rank's stderr goes to a temporary file
+    and is passed on when the rank ends; on failure the failing rank's last 40 lines are repeated under a header, so the
+    first real multi-GPU run can be diagnosed from its log.  `worker` (tests): the argv prefix to run instead of
+    [python, bench.py]."""
+    import tempfile
     port = os.environ.get("MASTER_PORT") or str(_free_port())
     cmd = list(worker) if worker else [sys.executable, os.path.abspath(__file__)]
-    procs = []
-    import tempfile
+    procs, errs = [], []
     out0 = tempfile.TemporaryFile(mode="w+")  # rank 0's stdout (a file, so a long line can never block on a pipe)
     for r in range(n):
         env = dict(os.environ)
@@ -209,8 +223,9 @@ def spawn_ranks(n, argv, worker=None, timeout=None, env_extra=None):
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port, "PP_BENCH_SPAWNED": "1"})
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.update(env_extra or {})
-        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=(out0 if r == 0 else subprocess.DEVNULL), stderr=None))
-    t_end = None if timeout is None else time.time() + timeout
+        errs.append(tempfile.TemporaryFile(mode="w+"))
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=(out0 if r == 0 else subprocess.DEVNULL), stderr=errs[r]))
+    t_end = None if not timeout else time.time() + float(timeout)
     failed = None
     while True:
         codes = [p.poll() for p in procs]
@@ -221,20 +236,31 @@ def spawn_ranks(n, argv, worker=None, timeout=None, env_extra=None):
         if all(c == 0 for c in codes):
             break
         if t_end is not None and time.time() > t_end:
-            failed = (-1, "timeout")
+            running = [r for r, c in enumerate(codes) if c is None]
+            failed = (running[0] if running else -1, "no exit within %.0f s (ranks still running: %s)" % (float(timeout), running))
             break
         time.sleep(0.05)
     if failed is not None:
         for p in procs:
             if p.poll() is None:
-                p.terminate()
+                p.terminate()          # by PID: only the children started above
         for p in procs:
             try:
                 p.wait(timeout=10)
             except subprocess.TimeoutExpired:
                 p.kill()
+                p.wait()
         sys.stderr.write("bench.py: rank %s failed (%s); %d-rank run aborted\n" % (failed[0], failed[1], n))
+        if 0 <= failed[0] < n:
+            sys.stderr.write("bench.py: ---- last lines of rank %d's stderr ----\n" % failed[0])
+            for ln in _tail(errs[failed[0]]):
+                sys.stderr.write("  [rank %d] %s\n" % (failed[0], ln))
+            sys.stderr.write("bench.py: ---- end of rank %d's stderr ----\n" % failed[0])
+        sys.stderr.flush()
         return 1
+    for r in range(n):  # a clean run: pass the ranks' stderr on (warnings, PP_DP_DEBUG bucket plans)
+        for ln in _tail(errs[r], 200):
+            sys.stderr.write("[rank %d] %s\n" % (r, ln))
     out0.seek(0)
     out = out0.read()
     line = None
@@ -269,6 +295,8 @@ def parse_args(argv=None):
     ap.add_argument("--backbone", default="resnet50", choices=["resnet50", "resnet101"],
                     help="resnet101 = the [3,4,23,3] variant of BASELINE configs[4] (with --height 540 --width 720 --classes 30)")
     ap.add_argument("--conv-mode", default=None, choices=["f32", "bf16x3"], help="default: env PP_CONV_MODE or bf16x3")
+    ap.add_argument("--rank-timeout", type=float, default=DEFAULT_RANK_TIMEOUT_S,
+                    help="--gpus N without a launcher: seconds after which ranks that have not exited are terminated (0 = none)")
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the short run of the other conv mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
@@ -284,7 +312,7 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: this process becomes the parent of N ranks (before torch is imported or any GPU call is made)
-        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], timeout=args.rank_timeout))
     main_worker(args)
 
 

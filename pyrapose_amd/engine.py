@@ -1144,7 +1144,7 @@ class Engine(object):
             return [(self.H, self.W)] * self.B if group is None else [(int(im.shape[0]), int(im.shape[1])) for im in group]
 
         held, self._next_dev = getattr(self, "_next_dev", None), None
-        if held is not None and held[0] == id(images_u8):
+        if held is not None and held[0] is images_u8:  # the host tensor itself is held: an id() could be reused by a new batch
             xd = held[1]  # uploaded by the previous call's look-ahead
         else:
             xd = images_u8 if images_u8.is_cuda else images_u8.cuda(non_blocking=True)
@@ -1152,7 +1152,7 @@ class Engine(object):
         if next_batch is not None and self.prefix_lane is not None:
             nimg = next_batch["images_u8"]
             nxd = nimg if nimg.is_cuda else nimg.cuda(non_blocking=True)
-            self._next_dev = (id(nimg), nxd)
+            self._next_dev = (nimg, nxd)
             nb = dict(images_u8=nxd, sizes_hw=sizes(next_batch.get("image_group")), transforms=next_batch.get("transforms"),
                       border=next_batch.get("border", "replicate"), cval=next_batch.get("cval", 0))
         if image_group is None:

@@ -106,9 +106,13 @@ class PyraPoseModel(object):
                     e.step_count = prev.step_count
             e._weights_version = -1
             engines[key] = e
+            # least recently used first out -- but never the plan in use, the one holding the freshest weights, or the most
+            # recent TRAINING plan: it is the only holder of the Adam moments and the step count (an evaluation pass over many
+            # image sizes between two training steps must not reset the optimizer)
+            keep_train = next((o for k, o in reversed(list(engines.items())) if k[3]), None)
             while len(engines) > self.MAX_ENGINES:
                 for k in list(engines):
-                    if engines[k] is not e and engines[k] is not cur:
+                    if engines[k] is not e and engines[k] is not cur and engines[k] is not keep_train:
                         engines.pop(k).close()
                         break
                 else:
@@ -207,16 +211,29 @@ class PyraPoseModel(object):
             self._engine._weights_version = self._weights_version
 
     def save_weights(self, filepath, format=None):
-        """format None / 'npz': numpy container, written under exactly the given name (the reference's snapshot names end in
-        '.h5'; load_weights recognises the container by content).  format 'h5': an HDF5 file in Keras-2.3.1's save_weights
-        layout (utils/hdf5_lite.py writer + the name mapping of utils/keras_names.py) -- what the reference's own
-        `load_weights(by_name=True)` would read; unverified against libhdf5 (none in this image)."""
-        if format == "h5":
-            from ..utils import hdf5_lite, keras_names
-            hdf5_lite.write_keras_weights(filepath, keras_names.tensors_to_keras(self.get_weights_dict()))
-            return
-        with open(filepath, "wb") as f:
-            np.savez(f, **self.get_weights_dict())
+        """format 'h5': an HDF5 file in Keras-2.3.1's save_weights layout (utils/hdf5_lite.py writer + the name mapping of
+        utils/keras_names.py) -- what the reference's own `load_weights(by_name=True)` reads.  format 'npz': the numpy
+        container.  format None: by the NAME, like Keras -- '.h5' / '.hdf5' / '.keras' (the reference's per-epoch snapshots,
+        bin/train.py:127-143) give HDF5, anything else the numpy container; PP_CHECKPOINT_NPZ=1 forces the container under any
+        name (load_weights recognises either by content).  The file appears under its name only when complete (written to a
+        temporary name beside it, then renamed)."""
+        if format is None:
+            ext = os.path.splitext(str(filepath))[1].lower()
+            format = "h5" if (ext in (".h5", ".hdf5", ".keras") and os.environ.get("PP_CHECKPOINT_NPZ") != "1") else "npz"
+        if format not in ("h5", "npz"):
+            raise ValueError("save_weights: format must be 'h5', 'npz' or None, got %r" % (format,))
+        tmp = "%s.tmp.%d" % (filepath, os.getpid())
+        try:
+            if format == "h5":
+                from ..utils import hdf5_lite, keras_names
+                hdf5_lite.write_keras_weights(tmp, keras_names.tensors_to_keras(self.get_weights_dict()))
+            else:
+                with open(tmp, "wb") as f:
+                    np.savez(f, **self.get_weights_dict())
+            os.replace(tmp, filepath)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
 
     save = save_weights
 
@@ -233,6 +250,9 @@ class PyraPoseModel(object):
         Returns [total, 3Dbox, cls, mask] like Keras."""
         if self._loss is None:
             raise RuntimeError("train_on_batch before compile()")
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            from ..parallel import ensure_process_group
+            ensure_process_group()  # selects this rank's GPU before the first .cuda() below
         xt = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, np.float32)).cuda()
         B, H, W, _ = xt.shape
         eng = self._get_engine(B, H, W, train=True)
@@ -252,6 +272,8 @@ class PyraPoseModel(object):
         # epoch still visits every batch once and a step consumes `world` of them (the global batch)
         world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
         if world > 1:
+            from ..parallel import ensure_process_group
+            ensure_process_group()  # this rank's GPU is current before the prefetcher or any .cuda() allocates
             steps = -(-steps // world)
         pick = (lambda i: generator[(i * world + rank) % len(generator)])
         history = {"loss": []}
@@ -293,9 +315,27 @@ class PyraPoseModel(object):
             history["loss"].append(logs["loss"])
             if hasattr(generator, "on_epoch_end"):
                 generator.on_epoch_end()
-            for cb in callbacks:
-                if hasattr(cb, "on_epoch_end"):
-                    cb.on_epoch_end(epoch, logs)
+            # data parallel: the replicas are identical, so the epoch-end work (snapshots, evaluation, LR schedule on the logs it
+            # produces) runs on rank 0 alone -- N ranks writing the same snapshot path at once would corrupt it; the others wait
+            # at the barrier and take rank 0's learning rate and stop flag
+            if world > 1:
+                import torch.distributed as dist
+                if rank == 0:
+                    for cb in callbacks:
+                        if hasattr(cb, "on_epoch_end"):
+                            cb.on_epoch_end(epoch, logs)
+                if dist.is_initialized():
+                    state = [float(self.lr or 0.0), bool(self.stop_training)] if rank == 0 else [None, None]
+                    dist.broadcast_object_list(state, src=0)
+                    if rank != 0:
+                        if self._optimizer is not None and state[0] != self.lr:
+                            self.set_lr(state[0])
+                        self.stop_training = state[1]
+                    dist.barrier()
+            else:
+                for cb in callbacks:
+                    if hasattr(cb, "on_epoch_end"):
+                        cb.on_epoch_end(epoch, logs)
             if self.stop_training:
                 break
         for cb in callbacks:

@@ -137,6 +137,34 @@ def split_planes3(ctx, src, hi, lo):
     check(lib.pp_split_planes_bf16x3(ctx.handle, src.numel(), _ptr(src), _ptr(hi), _ptr(lo)), ctx.handle, "pp_split_planes_bf16x3")
 
 
+# ---- "f16c8" arithmetic (csrc/conv2.hip): tensors in the H16L8 format, 3 bytes per element ----
+def new_hl(rows, ld, device="cuda"):
+    """A tensor [rows][ld] (ld % 64 == 0) in the H16L8 format: uint8 [rows, ld / 64, 192]."""
+    assert ld % 64 == 0, ld
+    return torch.zeros((rows, ld // 64, 192), dtype=torch.uint8, device=device)
+
+
+def split_hl(ctx, src, dst):
+    rows, ld = src.shape
+    check(lib.pp_split_h16l8(ctx.handle, rows, ld, _ptr(src), _ptr(dst)), ctx.handle, "pp_split_h16l8")
+    return dst
+
+
+def merge_hl(ctx, src, dst):
+    rows, ld = dst.shape
+    check(lib.pp_merge_h16l8(ctx.handle, rows, ld, _ptr(src), _ptr(dst)), ctx.handle, "pp_merge_h16l8")
+    return dst
+
+
+def conv_split_weights2(ctx, d, w, fwd, dgrad):
+    check(lib.pp_conv_split_weights_f16c8(ctx.handle, C.byref(d), _ptr(w), _ptr(fwd), _ptr(dgrad)), ctx.handle, "pp_conv_split_weights_f16c8")
+
+
+def conv_fwd2(ctx, d, x_hl, w_hl, bias, relu, y):
+    check(lib.pp_conv2d_nhwc_fwd_f16c8(ctx.handle, C.byref(d), _ptr(x_hl), _ptr(w_hl), _ptr(bias), int(bool(relu)), _ptr(y)), ctx.handle,
+          "pp_conv2d_nhwc_fwd_f16c8")
+
+
 def _set_capture(ctx, planes):
     if planes is not None:
         check(lib.pp_ctx_set_split_capture(ctx.handle, _ptr(planes[0]), _ptr(planes[1])), ctx.handle, "pp_ctx_set_split_capture")

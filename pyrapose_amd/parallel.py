@@ -22,6 +22,13 @@ def ensure_process_group(device=None):
     """WORLD_SIZE > 1 (the process was started by torch.distributed.run or bench.py's own launcher) and no process group yet:
     create the RCCL group (backend 'nccl'; PP_DIST_BACKEND=gloo for CPU / shared-card rehearsals).  Returns the world size."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        # the rank's GPU becomes the CURRENT device before anything allocates: without this the first x.cuda() of
+        # train_on_batch / the DevicePrefetcher of fit_generator would stage every rank's batches on cuda:0
+        # (PP_DIST_BACKEND=gloo rehearsals with several ranks on one card keep device 0)
+        local = int(device if device is not None else os.environ.get("LOCAL_RANK", "0"))
+        if torch.cuda.is_available() and local < torch.cuda.device_count():
+            torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("PP_DIST_BACKEND", "nccl")
@@ -31,6 +38,29 @@ def ensure_process_group(device=None):
         else:
             dist.init_process_group(backend)
     return world
+
+
+def bucket_bytes_from_env(default=32 << 20):
+    """PP_BUCKET_MB: size at which the flat gradient buffer is cut into all-reduce buckets (default 32 MB: ~6 buckets for the
+    169 MB of ResNet-50 gradients; xGMI is point to point, so fewer, larger collectives beat many small ones)."""
+    v = os.environ.get("PP_BUCKET_MB")
+    if not v:
+        return default
+    mb = float(v)
+    if not mb > 0:
+        raise ValueError("PP_BUCKET_MB must be positive, got %r" % v)
+    return int(mb * (1 << 20))
+
+
+def describe_buckets(buckets, bwd_ops=None):
+    """One line per bucket (launch order): float offsets, bytes, index (and name) of the backward launch that releases it."""
+    lines = ["gradient all-reduce plan: %d buckets, %.1f MB" % (len(buckets), sum(b - a for a, b, _ in buckets) * 4 / 2**20)]
+    for i, (a, b, r) in enumerate(buckets):
+        name = ""
+        if bwd_ops is not None and 0 <= r < len(bwd_ops):
+            name = " (%s)" % getattr(bwd_ops[r], "name", type(bwd_ops[r]).__name__)
+        lines.append("  bucket %d: floats [%d, %d) = %.2f MB, released after backward launch %d%s" % (i, a, b, (b - a) * 4 / 2**20, r, name))
+    return "\n".join(lines)
 
 
 def plan_buckets(entries, bwd_ops, bucket_bytes):
@@ -66,14 +96,18 @@ def plan_buckets(entries, bwd_ops, bucket_bytes):
 
 
 class DataParallel(object):
-    def __init__(self, engine, group=None, bucket_bytes=32 << 20):
+    def __init__(self, engine, group=None, bucket_bytes=None):
         self.eng, self.group = engine, group
+        bucket_bytes = bucket_bytes_from_env() if bucket_bytes is None else bucket_bytes
         self.active = dist.is_initialized()
         if not self.active and int(os.environ.get("WORLD_SIZE", "1")) > 1:
             raise RuntimeError("DataParallel: WORLD_SIZE=%s but torch.distributed is not initialised -- every rank would silently train "
                                "its own copy; call parallel.ensure_process_group() first" % os.environ["WORLD_SIZE"])
         self.world = dist.get_world_size(group) if self.active else 1
         self.buckets = plan_buckets(engine.params.entries, engine.bwd_ops, bucket_bytes)
+        if os.environ.get("PP_DP_DEBUG") == "1":
+            rank = dist.get_rank(group) if self.active else 0
+            print("[pyrapose_amd.parallel rank %d/%d] %s" % (rank, self.world, describe_buckets(self.buckets, engine.bwd_ops)), flush=True)
         self.by_op = {}
         for (a, b, r) in self.buckets:
             self.by_op.setdefault(r, []).append((a, b))

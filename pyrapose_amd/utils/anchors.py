@@ -139,7 +139,13 @@ def anchor_targets_bbox_device(anchors_dev, image_group, annotations_group, num_
             plane[i, : m.shape[0], : m.shape[1]] = m
         masks = torch.from_numpy(plane).cuda()
         if mask_transforms is not None:
+            # the reference (utils/image.py:216-230 apply_transform2mask + adjust_transform_for_mask) first resizes the mask
+            # to the image's size and re-centres the matrix on the MASK's own shape; warping with the image's matrix is the
+            # same operation only when mask and image have the same size -- refuse anything else instead of mis-aligning
             assert all(hw == mask_hw[0] for hw in mask_hw), "device mask augmentation needs equally sized masks"
+            assert all(tuple(mhw) == tuple(ihw) for mhw, ihw in zip(mask_hw, image_hw)), \
+                "device mask augmentation needs id masks of the image's size (got masks %s for images %s): resize them on the " \
+                "host as apply_transform2mask does, or pass mask_transforms=None" % (mask_hw, image_hw)
             masks = ops.warp_affine_u8(ctx, masks, mask_transforms, "nearest", "constant", 0)
     return ops.anchor_targets(ctx, anchors_dev, offs, dev(boxes), dev(labels), dev(box3d), dev(mids), masks, mask_hw, image_hw,
                               num_classes, mh, mw, negative_overlap, positive_overlap)

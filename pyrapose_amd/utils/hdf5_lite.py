@@ -9,10 +9,11 @@ the HDF5 File Format Specification (version 1.x structures named above) for exac
 compact new-style groups and compact / chunk-free layouts where they are trivial; anything else raises `H5Unsupported`
 (chunked or compressed datasets, variable-length data, dense attribute storage, shared messages).
 
-STATUS: written to the published specification and round-trip tested against the writer below (tests/test_hdf5_lite.py);
-NOT verified against a file produced by libhdf5 -- none exists in this image and none can be made here.  `tools/h5_to_npz.py`
-(h5py, run where the file was made) remains the reference route; `PyraPoseModel.load_weights` tries this reader on real
-HDF5 files and says so.
+STATUS: written to the published specification, round-trip tested against the writer below, and checked against the one
+libhdf5-written file this image holds: scipy's `testhdf5_7.4_GLNX86.mat` (MATLAB 7.4 = HDF5 1.6 behind a 512-byte user
+block: superblock version 0 found at offset 512 with base address 512, version-1 object header, old-style root group,
+version-2 data layout message, version-1 attribute with a fixed-length string) -- tests/test_hdf5_lite.py.  No file written
+by h5py / Keras itself exists here; `tools/h5_to_npz.py` (h5py, run where the file was made) remains the fallback route.
 
 The writer emits the same subset (one symbol-table node per group, sized by the superblock's leaf K): enough for
 `save_weights(..., format='h5')` checkpoints with Keras' layout and for the tests.
@@ -30,27 +31,58 @@ class H5Unsupported(NotImplementedError):
     pass
 
 
+def _guarded(fn):
+    """Structures that end early or point outside the file (a truncated download, a layout this module does not know) surface as
+    H5Unsupported -- never as struct.error / IndexError / a numpy buffer error from the middle of the parser."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*a, **kw):
+        try:
+            return fn(*a, **kw)
+        except H5Unsupported:
+            raise
+        except KeyError:
+            raise
+        except (struct.error, IndexError, OverflowError, ValueError, TypeError) as e:
+            raise H5Unsupported("malformed or unsupported HDF5 structure in %s: %s: %s" % (fn.__qualname__, type(e).__name__, e))
+    return wrapper
+
+
 # ------------------------------------------------------------------------------------------------ reader
+def find_superblock(data):
+    """Offset of the superblock: the signature sits at byte 0 or, behind a user block, at 512, 1024, 2048, ... (format
+    specification II.A: "the superblock may begin at certain predefined offsets ... 0, 512, 1024, 2048, and so on")."""
+    off = 0
+    while off + 8 <= len(data):
+        if bytes(data[off:off + 8]) == SIGNATURE:
+            return off
+        off = 512 if off == 0 else off * 2
+    return -1
+
+
 class _Reader(object):
     def __init__(self, data):
         self.b = data
-        if bytes(data[:8]) != SIGNATURE:
-            raise ValueError("not an HDF5 file (bad signature)")
-        ver = data[8]
+        sb = find_superblock(data)
+        if sb < 0:
+            raise ValueError("not an HDF5 file (no superblock signature at 0, 512, 1024, ...)")
+        self.superblock = sb
+        ver = data[sb + 8]
         if ver in (0, 1):
-            self.so, self.sl = data[13], data[14]
+            self.so, self.sl = data[sb + 13], data[sb + 14]
             if (self.so, self.sl) != (8, 8):
                 raise H5Unsupported("offsets / lengths of %d / %d bytes" % (self.so, self.sl))
-            p = 24 if ver == 0 else 28
-            self.base = self.u64(p)
+            p = sb + (24 if ver == 0 else 28)
+            self.base = self.u64(p)  # every address in the file is relative to this (= the user block's size when there is one)
             root_entry = p + 32
             self.root_header = self.u64(root_entry + 8)
         elif ver in (2, 3):
-            self.so, self.sl = data[9], data[10]
+            self.so, self.sl = data[sb + 9], data[sb + 10]
             if (self.so, self.sl) != (8, 8):
                 raise H5Unsupported("offsets / lengths of %d / %d bytes" % (self.so, self.sl))
-            self.base = self.u64(12)
-            self.root_header = self.u64(12 + 24)
+            self.base = self.u64(sb + 12)
+            self.root_header = self.u64(sb + 12 + 24)
         else:
             raise H5Unsupported("superblock version %d" % ver)
 
@@ -184,7 +216,7 @@ class _Reader(object):
     def group_entries(self, btree, heap):
         heap += self.base
         if self.b[heap:heap + 4] != b"HEAP":
-            raise ValueError("bad local heap signature")
+            raise H5Unsupported("bad local heap signature")
         seg = self.base + self.u64(heap + 24)
         out = OrderedDict()
 
@@ -206,12 +238,13 @@ class _Reader(object):
                     e = node + 8 + 40 * i
                     out[name_at(self.u64(e))] = self.u64(e + 8)
             else:
-                raise ValueError("bad group node signature %r" % bytes(sig))
+                raise H5Unsupported("bad group node signature %r" % bytes(sig))
         walk(btree)
         return out
 
 
 class _Object(object):
+    @_guarded
     def __init__(self, rd, addr, name):
         self._rd, self._addr, self.name = rd, addr, name
         self._msgs = rd.messages(addr)
@@ -231,6 +264,7 @@ class _Object(object):
 
 
 class Dataset(_Object):
+    @_guarded
     def read(self):
         rd = self._rd
         dt = shape = layout = None
@@ -246,9 +280,31 @@ class Dataset(_Object):
             elif t == 0x000B:
                 raise H5Unsupported("filtered (compressed) dataset %s" % self.name)
         if dt is None or shape is None or layout is None:
-            raise ValueError("%s is not a simple dataset" % self.name)
+            raise H5Unsupported("%s is not a simple dataset" % self.name)
         n = int(np.prod(shape)) if shape else 1
         ver = rd.u8(layout)
+        if ver in (1, 2):
+            # layout message of HDF5 <= 1.6 writers: version, dimensionality, class, 5 reserved bytes, [address], the
+            # dimensions as 4-byte numbers (contiguous / chunked: rank + 1 of them, the last one the element size), then for
+            # compact storage a 4-byte size and the data
+            ndim, cls = rd.u8(layout + 1), rd.u8(layout + 2)
+            if cls == 1:
+                addr = rd.u64(layout + 8)
+                dims = [rd.u32(layout + 16 + 4 * i) for i in range(ndim)]
+                size = int(np.prod(dims)) if dims else 0
+                if addr == UNDEF:
+                    return np.zeros(shape, dt.newbyteorder("="))
+                if size < n * dt.itemsize:
+                    raise H5Unsupported("dataset %s: %d bytes stored, %d needed" % (self.name, size, n * dt.itemsize))
+                arr = np.frombuffer(rd.b, dtype=dt, count=n, offset=rd.base + addr)
+            elif cls == 0:
+                o = layout + 8 + 4 * ndim
+                if rd.u32(o) < n * dt.itemsize:
+                    raise H5Unsupported("compact dataset %s: %d bytes stored, %d needed" % (self.name, rd.u32(o), n * dt.itemsize))
+                arr = np.frombuffer(rd.b, dtype=dt, count=n, offset=o + 4)
+            else:
+                raise H5Unsupported("chunked dataset %s" % self.name)
+            return arr.reshape(shape).astype(dt.newbyteorder("="), copy=True)
         if ver != 3:
             raise H5Unsupported("data layout message version %d" % ver)
         cls = rd.u8(layout + 1)
@@ -257,7 +313,7 @@ class Dataset(_Object):
             if addr == UNDEF:
                 return np.zeros(shape, dt.newbyteorder("="))
             if size < n * dt.itemsize:
-                raise ValueError("dataset %s: %d bytes stored, %d needed" % (self.name, size, n * dt.itemsize))
+                raise H5Unsupported("dataset %s: %d bytes stored, %d needed" % (self.name, size, n * dt.itemsize))
             arr = np.frombuffer(rd.b, dtype=dt, count=n, offset=rd.base + addr)
         elif cls == 0:
             arr = np.frombuffer(rd.b, dtype=dt, count=n, offset=layout + 4)
@@ -273,6 +329,7 @@ class Dataset(_Object):
 
 
 class Group(_Object):
+    @_guarded
     def _children(self):
         rd = self._rd
         out = OrderedDict()
@@ -329,7 +386,9 @@ class File(Group):
     def __init__(self, path):
         with open(path, "rb") as f:
             data = f.read()
-        rd = _Reader(data)  # (bytes: slicing copies only the few bytes asked for; np.frombuffer reads in place)
+        if find_superblock(data) < 0:
+            raise ValueError("%s is not an HDF5 file (no superblock signature at 0, 512, 1024, ...)" % path)
+        rd = _guarded(_Reader)(data)  # (bytes: slicing copies only the few bytes asked for; np.frombuffer reads in place)
         Group.__init__(self, rd, rd.root_header, "/")
 
     def __enter__(self):

@@ -24,7 +24,12 @@ STUB = textwrap.dedent("""
     with open(os.path.join(sys.argv[2], "seen%d" % rank), "w") as f:
         f.write(" ".join(sys.argv[3:]))
     if mode == "fail" and rank == 1:
+        for i in range(60):
+            sys.stderr.write("rank1 diagnostic line %d\\n" % i)
+        sys.stderr.flush()
         sys.exit(3)
+    if mode == "hang":
+        time.sleep(60)   # e.g. a rank stuck in RCCL initialisation: the parent's timeout must end the run
     if mode == "fail":
         time.sleep(60)   # a rank that would hang on the dead peer's collective: the parent must terminate it
     if rank == 0:
@@ -33,10 +38,10 @@ STUB = textwrap.dedent("""
 """)
 
 
-def _run(tmp_path, mode, n, capsys):
+def _run(tmp_path, mode, n, capsys, timeout=120):
     stub = tmp_path / "stub.py"
     stub.write_text(STUB)
-    rc = bench.spawn_ranks(n, ["--gpus", str(n), "--steps", "2"], worker=[sys.executable, str(stub), mode, str(tmp_path)], timeout=120)
+    rc = bench.spawn_ranks(n, ["--gpus", str(n), "--steps", "2"], worker=[sys.executable, str(stub), mode, str(tmp_path)], timeout=timeout)
     return rc, capsys.readouterr()
 
 
@@ -54,6 +59,30 @@ def test_spawn_fails_when_a_rank_fails(tmp_path, capsys):
     rc, io = _run(tmp_path, "fail", 2, capsys)
     assert rc != 0 and io.out.strip() == ""
     assert "rank 1 failed" in io.err
+
+
+def test_spawn_relays_the_failing_ranks_last_stderr_lines(tmp_path, capsys):
+    rc, io = _run(tmp_path, "fail", 2, capsys)
+    assert rc != 0
+    relayed = [l for l in io.err.splitlines() if l.startswith("  [rank 1] ")]
+    assert len(relayed) == 40                                   # the LAST 40 of the 60 lines the rank wrote
+    assert relayed[0].endswith("diagnostic line 20") and relayed[-1].endswith("diagnostic line 59")
+
+
+def test_spawn_times_out_instead_of_hanging(tmp_path, capsys):
+    import time
+    t0 = time.time()
+    rc, io = _run(tmp_path, "hang", 2, capsys, timeout=3)
+    assert rc != 0 and io.out.strip() == ""
+    assert time.time() - t0 < 30                                # the ranks were terminated by PID, not waited for
+    assert "no exit within 3 s" in io.err and "ranks still running: [0, 1]" in io.err
+
+
+def test_spawn_has_a_default_timeout():
+    import inspect
+    assert inspect.signature(bench.spawn_ranks).parameters["timeout"].default == bench.DEFAULT_RANK_TIMEOUT_S == 900.0
+    assert bench.parse_args(["--gpus", "2"]).rank_timeout == 900.0
+    assert bench.parse_args(["--gpus", "2", "--rank-timeout", "60"]).rank_timeout == 60.0
 
 
 def test_spawn_rejects_a_line_with_another_world_size(tmp_path, capsys):

@@ -19,11 +19,38 @@ def test_model_checkpoint_redirect_and_reload(tmp_path):
     cp.on_epoch_end(0, {"loss": 1.0})
     cp.on_epoch_end(1, {"loss": 0.5})
     files = sorted(os.listdir(str(tmp_path)))
-    assert files == ["resnet50_linemod_01.h5", "resnet50_linemod_02.h5"]  # exactly the reference's names
+    assert files == ["resnet50_linemod_01.h5", "resnet50_linemod_02.h5"]  # exactly the reference's names, no temporary left behind
+    for f in files:  # '.h5' snapshots ARE HDF5 files in Keras' save_weights layout (what a Keras user can open)
+        with open(os.path.join(str(tmp_path), f), "rb") as fh:
+            assert fh.read(8) == b"\x89HDF\r\n\x1a\n"
+    from pyrapose_amd.utils import hdf5_lite
+    assert "layer_names" in hdf5_lite.File(os.path.join(str(tmp_path), files[0])).attrs
     loaded = models.load_model(os.path.join(str(tmp_path), files[1]), backbone_name="resnet50")
     w0, w1 = model.get_weights_dict(), loaded.get_weights_dict()
     assert set(w0) == set(w1) and all(np.array_equal(w0[k], w1[k]) for k in w0)
     assert w0["reg_conv0/kernel"].shape == (3, 3, 256, 512)  # Keras HWIO
+
+
+def test_checkpoint_container_escape_and_formats(tmp_path, monkeypatch):
+    model = models.backbone("resnet50").retinanet(num_classes=2)
+    a = os.path.join(str(tmp_path), "a.h5")
+    monkeypatch.setenv("PP_CHECKPOINT_NPZ", "1")                 # the escape: numpy container under the '.h5' name
+    model.save(a)
+    with open(a, "rb") as fh:
+        assert fh.read(2) == b"PK"
+    monkeypatch.delenv("PP_CHECKPOINT_NPZ")
+    b = os.path.join(str(tmp_path), "b.npz")
+    model.save_weights(b)                                        # other names: the container
+    with open(b, "rb") as fh:
+        assert fh.read(2) == b"PK"
+    with pytest.raises(ValueError):
+        model.save_weights(os.path.join(str(tmp_path), "c.h5"), format="hdf")
+    for path in (a, b):
+        m = models.backbone("resnet50").retinanet(num_classes=2)
+        m._weights = {k: np.zeros_like(v) for k, v in m.get_weights_dict().items()}
+        m.load_weights(path)
+        assert np.array_equal(m.get_weights_dict()["P4/kernel"], model.get_weights_dict()["P4/kernel"])
+    assert sorted(os.listdir(str(tmp_path))) == ["a.h5", "b.npz"]
 
 
 def test_checkpoint_save_best_only_and_period(tmp_path):

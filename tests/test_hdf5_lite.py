@@ -82,3 +82,56 @@ def test_other_dtypes_and_big_endian_and_refusals(tmp_path):
         f.write(b"PK\x03\x04 not hdf5")
     with pytest.raises(ValueError):
         H5.File(bad)
+
+
+def _matlab_hdf5_file():
+    import os
+    try:
+        import scipy
+    except ImportError:
+        return None
+    p = os.path.join(os.path.dirname(scipy.__file__), "io", "matlab", "tests", "data", "testhdf5_7.4_GLNX86.mat")
+    return p if os.path.exists(p) else None
+
+
+@pytest.mark.skipif(_matlab_hdf5_file() is None, reason="scipy's testhdf5_7.4_GLNX86.mat is not installed")
+def test_reads_a_file_written_by_libhdf5_behind_a_user_block():
+    """Third-party evidence for the reader: the one libhdf5-written file of this image.  MATLAB 7.4 '-v7.3' = HDF5 1.6 behind a
+    512-byte user block.  Its content is MATLAB's `testdouble` variable, which scipy documents as
+    theta = pi/4 * arange(9) (scipy/io/matlab/tests/test_mio.py: `theta`, case_table4 'double'; class 'double'), stored
+    column-major, i.e. as a (9, 1) HDF5 dataset."""
+    path = _matlab_hdf5_file()
+    with open(path, "rb") as fh:
+        raw = fh.read()
+    assert raw[:6] == b"MATLAB" and H5.find_superblock(raw) == 512           # user block first, superblock at the second probe offset
+    f = H5.File(path)
+    assert f._rd.superblock == 512 and f._rd.base == 512                    # addresses are relative to the base address
+    assert f.keys() == ["testdouble"]
+    d = f["testdouble"]
+    assert isinstance(d, H5.Dataset) and d.shape == (9, 1)
+    a = d.read()
+    assert a.dtype == np.float64 and a.shape == (9, 1)
+    assert np.array_equal(a.ravel(), np.pi / 4 * np.arange(9, dtype=float))   # bit-exact: MATLAB computed the same doubles
+    assert d.attrs["MATLAB_class"] == b"double"                              # fixed-length string attribute (6 bytes, scalar space)
+    # the same bytes without the user block are a different file (every address moves by 512): refused cleanly, not mis-read
+    with pytest.raises((H5.H5Unsupported, ValueError, KeyError)):
+        import tempfile
+        with tempfile.NamedTemporaryFile(suffix=".h5") as t:
+            t.write(raw[512:])
+            t.flush()
+            H5.File(t.name)["testdouble"].read()
+
+
+def test_truncated_files_raise_h5unsupported_not_struct_errors(tmp_path):
+    path = str(tmp_path / "t.h5")
+    H5.write_keras_weights(path, {"l": {"l/a:0": np.arange(600, dtype=np.float32)}})
+    with open(path, "rb") as f:
+        raw = f.read()
+    for cut in (100, 200, len(raw) // 2, len(raw) - 100):
+        bad = str(tmp_path / ("cut%d.h5" % cut))
+        with open(bad, "wb") as f:
+            f.write(raw[:cut])
+        try:
+            H5.read_keras_weights(bad)
+        except (H5.H5Unsupported, KeyError):
+            pass                                                            # the only exceptions a caller has to expect

@@ -52,6 +52,26 @@ def test_plan_buckets_covers_trainable_range_once():
     assert spans[0][0] >= entries["t1"]["offset"] + entries["t1"]["count"]
 
 
+def test_bucket_size_from_env_and_plan_description(monkeypatch):
+    from pyrapose_amd import parallel
+    monkeypatch.delenv("PP_BUCKET_MB", raising=False)
+    assert parallel.bucket_bytes_from_env() == 32 << 20
+    monkeypatch.setenv("PP_BUCKET_MB", "8")
+    assert parallel.bucket_bytes_from_env() == 8 << 20
+    monkeypatch.setenv("PP_BUCKET_MB", "0")
+    with pytest.raises(ValueError):
+        parallel.bucket_bytes_from_env()
+
+    class Op(object):
+        def __init__(self, name, wrange=None):
+            self.name, self.wrange = name, wrange
+    text = parallel.describe_buckets([(100, 300, 1), (0, 100, 2)], [Op("a"), Op("wgrad:reg_out", (100, 300)), Op("wgrad:P3", (0, 100))])
+    lines = text.splitlines()
+    assert lines[0].startswith("gradient all-reduce plan: 2 buckets")
+    assert "floats [100, 300)" in lines[1] and "launch 1 (wgrad:reg_out)" in lines[1]
+    assert "floats [0, 100)" in lines[2] and "launch 2 (wgrad:P3)" in lines[2]
+
+
 def test_bucket_cut_between_kernel_and_bias_waits_for_the_layers_launch():
     """A weight-gradient launch writes its layer's kernel AND bias slot.  With a bucket size that puts the cut between the two,
     BOTH buckets must wait for that launch (the bias sits in the earlier bucket of the layout walk)."""

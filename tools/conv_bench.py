@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--shape", default="reg")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--mode", default="fwd,dgrad,wgrad")
+    ap.add_argument("--check", action="store_true", help="print the error of the forward modes against a float64 convolution")
     args = ap.parse_args()
     ctx = ops.Context(0)
     if os.environ.get("PP_SPLITK_MB"):
@@ -107,7 +108,14 @@ def main():
         skip_p = ops.row_block_list(ctx, dys, cout)
         sh, sl = ops.new_planes(rows, ld_w)
         ops.split_planes3(ctx, dys, sh, sl)
-        fns = {"fwd3pp": lambda: ops.conv_fwd3(ctx, d, None, fh, fl, bias, None, True, None, x_planes=(xh, xl), y_planes=(yh, yl)),
+        x_hl = w_hl = None
+        if cin % 64 == 0 and k == 3 and stride == 1:
+            x_hl = ops.split_hl(ctx, x, ops.new_hl(rows_in, cin))
+            w_hl = torch.zeros((taps, cout, cin // 64, 192), dtype=torch.uint8, device="cuda")
+            ops.conv_split_weights2(ctx, d, w, w_hl, None)
+        fns = {"fwd2": lambda: ops.conv_fwd2(ctx, d, x_hl, w_hl, bias, True, y),
+               "splithl": lambda: ops.split_hl(ctx, x, x_hl),
+               "fwd3pp": lambda: ops.conv_fwd3(ctx, d, None, fh, fl, bias, None, True, None, x_planes=(xh, xl), y_planes=(yh, yl)),
                "dgrad3pp": lambda: ops.conv_bwd_data3(ctx, d, None, dh, dl, None, None, None, dy_planes=(gh, gl), dx_planes=(dxh, dxl),
                                                       relu_src_hi=xh),
                "dgrad3sp": lambda: ops.conv_bwd_data3(ctx, d, None, dh, dl, None, None, None, dy_planes=(sh, sl), dx_planes=(dxh, dxl),
@@ -146,6 +154,17 @@ def main():
             tf = flops / us / 1e6
             print("%-7s %-6s rows=%d cin=%d cout=%d k=%d  %.1f us  %.1f TFLOP/s  %.1f%% of f32-MFMA peak" %
                   (name, mode, rows, cin, cout, k, us, tf, 100 * tf / 157.3), flush=True)
+            if args.check and mode in ("fwd", "fwd3", "fwd3p", "fwd2"):
+                # error of the launch against float64 (torch on the device, a sample of the output rows of the first level)
+                import torch.nn.functional as F
+                h0, w0 = shapes[0]
+                xi = x[: h0 * w0].double().reshape(1, h0, w0, cin).permute(0, 3, 1, 2)
+                wt = w[:, :cout].double().reshape(k, k, cin, cout).permute(3, 2, 0, 1)
+                ref = F.relu(F.conv2d(xi, wt, None, stride=stride, padding=pad)).permute(0, 2, 3, 1).reshape(-1, cout)
+                got = y[: ref.shape[0], :cout].double()
+                err = (got - ref)
+                print("        vs float64 (image 0, level 0): rel-L2 %.3e  max|err|/max|ref| %.3e" %
+                      (float(err.norm() / ref.norm()), float(err.abs().max() / ref.abs().max())), flush=True)
 
 
 if __name__ == "__main__":
