@@ -164,16 +164,18 @@ __global__ void split_weights_hl_kernel(int cin, int cout, int ld_w, const float
 // 6h + 4, 6h + 5 (its 32 lo bytes); the h = 1 group starts 32 banks off the h = 0 group, the slot pitch is 8 banks off a
 // multiple of 64: the 16-byte stores of a staging quad-pair and the 512-byte fragment reads are conflict-free.
 // Row `rows` of every slot stays zero: a padded tap reads it (one select of the base address per tap and row block).
-template <int TM, int TN, int DB>
-__global__ __launch_bounds__(256, 2) void igemm2x_kernel(const IgemmParams p, const void* __restrict__ g_a, unsigned a_bytes,
+// WR: rows of the wave grid (2 columns): 2 * WR waves, tile 32 TM WR x 64 TN.  WR = 2: 128x128, 4 waves, two workgroups per CU.
+// WR = 4: 256x128, 8 waves, ONE workgroup per CU (100 KB of LDS): the weight tile is staged once for twice the MFMAs.
+template <int TM, int TN, int DB, int WR = 2>
+__global__ __launch_bounds__(128 * WR, WR == 2 ? 2 : 1) void igemm2x_kernel(const IgemmParams p, const void* __restrict__ g_a, unsigned a_bytes,
                                                          const void* __restrict__ g_w, unsigned w_bytes, const float* __restrict__ g_bias,
                                                          float* __restrict__ g_out, int w_rows, int w_groups) {
-  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int BM = 32 * TM * WR, BN = 64 * TN, NT = 128 * WR, RS = NT / 4;  // RS: rows staged per pass
   constexpr int PA = BM + 2, PB = BN + 2;          // slot pitch in 16-byte units
   constexpr int HA = 6 * PA + 12, HB = 6 * PB + 12;  // start of the h = 1 slot group
   constexpr int A_U4 = 12 * PA + 12, B_U4 = 12 * PB + 12;
   constexpr int SMEM_U4 = A_U4 + (DB != 0 ? 2 : 1) * B_U4;  // DB: the weight tile is double-buffered, one barrier per tap
-  __shared__ __attribute__((aligned(16))) uint4 smem[SMEM_U4];
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];  // SMEM_U4 of them (dynamic: the 8-wave form needs 100 KB)
   uint4* As = smem;
   uint4* Bs0 = smem + A_U4;
 
@@ -192,10 +194,11 @@ __global__ __launch_bounds__(256, 2) void igemm2x_kernel(const IgemmParams p, co
 
   // staged rows r0 + 64 i: byte offset of the dx = 0 source pixel at ty = 0 (+ this thread's piece), row pitch | validity per ty
   const int row_bytes = p.ld_src * 3;
-  int s_base[TM], s_pitch[TM];
+  constexpr int PA_N = BM / RS, PB_N = BN / RS;  // staging passes over the gathered / the weight tile
+  int s_base[PA_N], s_pitch[PA_N];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int q = m0 + r0 + 64 * i;
+  for (int i = 0; i < PA_N; ++i) {
+    const int q = m0 + r0 + RS * i;
     const RowPos r = decode_row(p, q < 0 ? 0 : q);
     const bool ok = q >= 0 && r.ok;
     const int x = r.xbase - p.off_x;
@@ -221,10 +224,10 @@ __global__ __launch_bounds__(256, 2) void igemm2x_kernel(const IgemmParams p, co
       }
     f_valid[a >> 1] |= v << (16 * (a & 1));
   }
-  int b_base[TN];
+  int b_base[PB_N];
 #pragma unroll
-  for (int i = 0; i < TN; ++i) {
-    const int n = n0 + r0 + 64 * i;
+  for (int i = 0; i < PB_N; ++i) {
+    const int n = n0 + r0 + RS * i;
     b_base[i] = n < w_rows ? n * w_groups * 192 + 16 * oct : PP_BUF_OOB;
   }
   const int b_tap = w_rows * w_groups * 192;
@@ -240,11 +243,11 @@ __global__ __launch_bounds__(256, 2) void igemm2x_kernel(const IgemmParams p, co
     }
   }
 
-  uint4 ra[TM][3], rb[TN][3];
+  uint4 ra[PA_N][3], rb[PB_N][3];
   int ty = 0, chunk = 0;  // group being LOADED
   auto load_a = [&]() {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < PA_N; ++i) {
       int vo = s_base[i] + __mul24(ty, s_pitch[i] & ~15) + chunk * 192;
       vo = ((s_pitch[i] >> ty) & 1) ? vo : PP_BUF_OOB;
 #pragma unroll
@@ -254,22 +257,22 @@ __global__ __launch_bounds__(256, 2) void igemm2x_kernel(const IgemmParams p, co
   auto load_b = [&](int tx) {
     const int b_uni = ((p.w_ty0 + ty) * p.w_kw + tx) * b_tap + chunk * 192;
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
+    for (int i = 0; i < PB_N; ++i)
 #pragma unroll
       for (int q = 0; q < 3; ++q) rb[i][q] = buf_load16(rs_w, b_base[i], b_uni + 64 * q);
   };
   auto store_a = [&]() {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < PA_N; ++i)
 #pragma unroll
-      for (int q = 0; q < 3; ++q) As[st_a[q] + 64 * i] = ra[i][q];
+      for (int q = 0; q < 3; ++q) As[st_a[q] + RS * i] = ra[i][q];
   };
   auto store_b = [&](int buf) {
     uint4* Bs = Bs0 + buf * B_U4;
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
+    for (int i = 0; i < PB_N; ++i)
 #pragma unroll
-      for (int q = 0; q < 3; ++q) Bs[st_b[q] + 64 * i] = rb[i][q];
+      for (int q = 0; q < 3; ++q) Bs[st_b[q] + RS * i] = rb[i][q];
   };
 
   floatx16 acc[TM][TN];
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void igemm2x_kernel(const IgemmParams p, co
 
   // ---- epilogue through LDS: + bias, ReLU, f32 rows of 16 bytes per lane (halo rows 0 and BM - 1 are not written) ----
   float* stage = reinterpret_cast<float*>(smem);
-  constexpr int C4 = BN / 4, RPI = 256 / C4, ROWS = 32 * TM, SWEEPS = ROWS / RPI;
+  constexpr int C4 = BN / 4, RPI = NT / C4, ROWS = 32 * TM, SWEEPS = ROWS / RPI;
   static_assert(ROWS * BN * 4 <= SMEM_U4 * 16, "epilogue staging does not fit");
   const int e_c4 = tid % C4, e_r = tid / C4;
   const int co = n0 + 4 * e_c4;
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void igemm2x_kernel(const IgemmParams p, co
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (g_bias && col_ok) bias4 = *reinterpret_cast<const float4*>(g_bias + co);
 #pragma unroll
-  for (int hm = 0; hm < 2; ++hm) {
+  for (int hm = 0; hm < WR; ++hm) {
     __syncthreads();
     if (wm == hm) {
 #pragma unroll
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(256, 2) void igemm2x_kernel(const IgemmParams p, co
     }
     __syncthreads();
     if (col_ok) {
-#pragma unroll 4
+#pragma unroll
       for (int s = 0; s < SWEEPS; ++s) {
         const int row = e_r + RPI * s;
         const int trow = hm * 32 * TM + row;
@@ -558,16 +561,19 @@ extern "C" int pp_conv2d_nhwc_fwd_f16c8(pp_ctx* ctx, const pp_conv_desc* d, cons
   for (int i = 0; i < p.n_seg; ++i) max_sw = p.seg[i].SW > max_sw ? p.seg[i].SW : max_sw;
   PP_CHECK_ARG(ctx, same && a_bytes < (1ll << 31) && w_bytes < (1ll << 31) && (long long)max_sw * p.ld_src * 3 < (1ll << 23), PP_ERR_SHAPE,
                "pp_conv2d_nhwc_fwd_f16c8: (prototype) 3-wide stride-1 'same' convolutions below 2 GiB only");
-  constexpr int TM = 2, TN = 2, BM = 64 * TM, BN = 64 * TN;
-  p.n_tiles_n = (p.Nout + BN - 1) / BN;
-  const int n_tiles_mx = (p.M + BM - 3) / (BM - 2);
   static const int db = []() { const char* e = getenv("PP_CONV2_DB"); return e ? atoi(e) : 1; }();
-  if (db)
-    hipLaunchKernelGGL((igemm2x_kernel<TM, TN, 1>), dim3((unsigned)(n_tiles_mx * p.n_tiles_n)), dim3(256), 0, ctx->stream, p, x_hl,
-                       (unsigned)a_bytes, w_hl, (unsigned)w_bytes, bias, y, d->cout, d->cin / 64);
-  else
-    hipLaunchKernelGGL((igemm2x_kernel<TM, TN, 0>), dim3((unsigned)(n_tiles_mx * p.n_tiles_n)), dim3(256), 0, ctx->stream, p, x_hl,
-                       (unsigned)a_bytes, w_hl, (unsigned)w_bytes, bias, y, d->cout, d->cin / 64);
+  static const int wr = []() { const char* e = getenv("PP_CONV2_WR"); return e ? atoi(e) : 2; }();
+  auto launch = [&](auto kern, int bm, int bn, int threads, size_t smem_bytes) {
+    p.n_tiles_n = (p.Nout + bn - 1) / bn;
+    const int n_tiles_mx = (p.M + bm - 3) / (bm - 2);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_tiles_mx * p.n_tiles_n)), dim3(threads), smem_bytes, ctx->stream, p, x_hl, (unsigned)a_bytes, w_hl,
+                       (unsigned)w_bytes, bias, y, d->cout, d->cin / 64);
+  };
+  auto smem_of = [](int bm, int bn, int nb) { return (size_t)((12 * (bm + 2) + 12) + nb * (12 * (bn + 2) + 12)) * 16; };
+  if (wr == 4) launch(igemm2x_kernel<2, 2, 1, 4>, 256, 128, 512, smem_of(256, 128, 2));
+  else if (db) launch(igemm2x_kernel<2, 2, 1, 2>, 128, 128, 256, smem_of(128, 128, 2));
+  else launch(igemm2x_kernel<2, 2, 0, 2>, 128, 128, 256, smem_of(128, 128, 1));
   PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_fwd_f16c8");
   return PP_OK;
 }

@@ -6,9 +6,9 @@ shapes=${2:-reg,cls}
 for rep in 1 2; do
   echo "== rep $rep" >> $out
   timeout -k 10 200 python tools/conv_bench.py --shape $shapes --mode fwd3p --check >> $out 2>&1 || exit 1
-  for db in 0 1; do
-    echo "-- PP_CONV2_DB=$db" >> $out
-    PP_CONV2_DB=$db timeout -k 10 200 python tools/conv_bench.py --shape $shapes --mode fwd2 --check >> $out 2>&1 || exit 1
+  for wr in 2 4; do
+    echo "-- PP_CONV2_WR=$wr" >> $out
+    PP_CONV2_WR=$wr timeout -k 10 200 python tools/conv_bench.py --shape $shapes --mode fwd2 --check >> $out 2>&1 || exit 1
   done
 done
 grep -v amdgpu.ids $out
