@@ -38,11 +38,18 @@ def _train_step_vs_oracle(ctx, B, H, W, C, x, targets, Wt, backbone="resnet50", 
     torch.cuda.synchronize()
     got = eng.losses()
     yb, yc, ym = [t.cpu().numpy() for t in tg]
+    # head outputs: against the oracle's OWN forward (its own ReLU decisions, relu_masks=None), float64 -- no self-reference
+    with torch.no_grad():
+        free = MT.forward(Wt, x, C, torch.float64, blocks=blocks, relu_masks=None)
+    w = {"3Dbox": assert_rows_within(reg, free["3Dbox"].numpy(), "3Dbox (unmasked oracle forward)"),
+         "cls": assert_rows_within(cls, free["cls"].numpy(), "cls (unmasked oracle forward)"),
+         "mask": assert_rows_within(mask, free["mask"].numpy(), "mask (unmasked oracle forward)")}
+    del free
+    # losses and gradients: the oracle differentiates the smooth piece of the loss the engine was on (its ReLU pattern pinned)
     losses_ref, g_ref, ref = MT.loss_and_grads(Wt, x, yb, yc, ym, C, torch.float64, blocks=blocks,
                                                relu_masks=engine_relu_masks(eng), loss_params=loss_params)
-    w = {"3Dbox": assert_rows_within(reg, ref["3Dbox"].detach().numpy(), "3Dbox"),
-         "cls": assert_rows_within(cls, ref["cls"].detach().numpy(), "cls"),
-         "mask": assert_rows_within(mask, ref["mask"].detach().numpy(), "mask")}
+    for k, got_rows in (("3Dbox", reg), ("cls", cls), ("mask", mask)):
+        assert_rows_within(got_rows, ref[k].detach().numpy(), k + " (pinned ReLU pattern)")
     for k in ("3Dbox", "cls", "mask", "l2"):
         assert abs(got[k] - losses_ref[k]) <= 1e-4 * max(abs(losses_ref[k]), 1e-3), (k, got[k], losses_ref[k])
     worst, total = assert_grads_within(eng, g_ref, Wt, 1e-3)
