@@ -57,9 +57,11 @@ def main():
     ap.add_argument("--shape", default="reg")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--mode", default="fwd,dgrad,wgrad")
+    ap.add_argument("--fmt", type=int, default=0, help="plane format of the *3p modes: 0 bf16 pairs (bf16x3), 1 P16 (f16c8 arithmetic)")
     ap.add_argument("--check", action="store_true", help="print the error of the forward modes against a float64 convolution")
     args = ap.parse_args()
     ctx = ops.Context(0)
+    ops.set_planes_format(ctx, args.fmt)
     if os.environ.get("PP_SPLITK_MB"):
         ctx.set_workspace(int(os.environ["PP_SPLITK_MB"]) << 20)
     for name in args.shape.split(","):
@@ -154,6 +156,17 @@ def main():
             tf = flops / us / 1e6
             print("%-7s %-6s rows=%d cin=%d cout=%d k=%d  %.1f us  %.1f TFLOP/s  %.1f%% of f32-MFMA peak" %
                   (name, mode, rows, cin, cout, k, us, tf, 100 * tf / 157.3), flush=True)
+            if args.check and mode in ("wgrad3p", "wgrad3", "wgrad") and k == 3 and stride == 1:
+                # the centre tap of the weight gradient against float64: dW[1][1] = x^T dy over all rows (no shift, no padding)
+                dw.zero_()
+                fn()
+                torch.cuda.synchronize()
+                c = (k * k) // 2
+                ref = x.double().t() @ dy[:, :cout].double()
+                got = dw[c * cin:(c + 1) * cin, :cout].double()
+                err = got - ref
+                print("        centre tap vs float64: rel-L2 %.3e  max|err|/max|ref| %.3e" %
+                      (float(err.norm() / ref.norm()), float(err.abs().max() / ref.abs().max())), flush=True)
             if args.check and mode in ("fwd", "fwd3", "fwd3p", "fwd2"):
                 # error of the launch against float64 (torch on the device, a sample of the output rows of the first level)
                 import torch.nn.functional as F
