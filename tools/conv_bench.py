@@ -57,11 +57,9 @@ def main():
     ap.add_argument("--shape", default="reg")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--mode", default="fwd,dgrad,wgrad")
-    ap.add_argument("--fmt", type=int, default=0, help="plane format of the *3p modes: 0 bf16 pairs (bf16x3), 1 P16 (f16c8 arithmetic)")
     ap.add_argument("--check", action="store_true", help="print the error of the forward modes against a float64 convolution")
     args = ap.parse_args()
     ctx = ops.Context(0)
-    ops.set_planes_format(ctx, args.fmt)
     if os.environ.get("PP_SPLITK_MB"):
         ctx.set_workspace(int(os.environ["PP_SPLITK_MB"]) << 20)
     for name in args.shape.split(","):
