@@ -168,6 +168,15 @@ int pp_ctx_set_row_block_out(pp_ctx* ctx, const unsigned char* flags, int* list)
 /* f32 tensor of n elements (n % 8 == 0) -> bf16 (hi, lo) planes with the same [rows][ld] geometry.  Convs that are
  * given planes for their gathered operand skip the conversion inside the kernel (the f32 pointer may then be NULL). */
 int pp_split_planes_bf16x3(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo);
+/* The gradient chain travels multiplied by a power of two (the hi plane holds IEEE halves, which stop at 6e-8; loss gradients are
+ * ~1e-7): pp_grad_scale_from_counts writes scale2 = {2^G, 2^-G} with 2^G = 2^8 * 2^floor(log2(max(1, min_i counts[i]))) -- every loss
+ * gradient of losses.py:22-68 / :321-408 is bounded by ~1 / max(1, positives of its head); pp_split_planes_scaled_bf16x3 is
+ * pp_split_planes_bf16x3 of src * scale_dev[0] (the three loss gradients); every gradient a bwd-data launch or a pointwise kernel
+ * derives from them carries the same factor; pp_ctx_set_grad_scale (persistent; NULL = none) makes the weight-gradient launches of
+ * this context multiply dW / dbias by scale2[1] when their operands are planes. */
+int pp_grad_scale_from_counts(pp_ctx* ctx, const int* counts_dev, int n_counts, float* scale2_dev);
+int pp_split_planes_scaled_bf16x3(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo, const float* scale_dev);
+int pp_ctx_set_grad_scale(pp_ctx* ctx, const float* scale2_dev);
 
 /* ---- "f16c8" arithmetic (csrc/conv2.hip): x*w ~= x_hi*w_hi (f16 MFMA) + (x_hi8*w_lo8 + x_lo8*w_hi8) * 2^-12 (block-scaled e5m2
  * MFMA at twice the rate): two matrix-core units per product instead of the three of bf16x3, ~3e-5 relative error per

@@ -1,54 +1,116 @@
-// Implicit-GEMM convolution with float32-class accuracy on the bf16 matrix cores ("bf16x3"):
-//   x = x_hi + x_lo,  w = w_hi + w_lo  (bf16 round-to-nearest of the value and of its remainder)
-//   x*w ~= x_hi*w_hi + x_hi*w_lo + x_lo*w_hi      (dropped: x_lo*w_lo and the second remainders, ~2^-16 relative)
-// Three v_mfma_f32_32x32x16_bf16 per 16-deep k-step accumulate in f32: 5.3x the per-clock rate of the exact
-// f32 MFMA (64 FLOP/clk/SIMD) at ~1.5e-5 relative error per product, which keeps the whole graph inside the
-// 1e-3 head-output bar (tests/test_gpu_model.py, mode bf16x3).  Same gather, row spaces, fusions and LDS-staged
-// epilogue as conv.hip.  Activations stay float32 in HBM: the A tile is split into hi/lo while it is staged into
-// LDS (3 VALU per element, under the MFMAs of the other waves); weights are split once per optimizer step by
-// pp_conv_split_weights_bf16x3 into k-contiguous bf16 planes (forward: [tap][cout][cin], bwd-data: [tap][cin][cout]).
+// Implicit-GEMM convolution with float32-class accuracy at TWO matrix-core units per product ("f16c8"; rounds 1-2 used three
+// bf16 MFMAs per product, "bf16x3": the entry points keep that name):
+//   x = x_hi + x_lo:  x_hi = f16(x) (11-bit significand, |x| saturates at 65504),  x_lo8 = e5m2((x - x_hi) * 2^12);  same for w
+//   x*w ~= x_hi*w_hi                                 v_mfma_f32_32x32x16_f16
+//        + (x_hi8*w_lo8 + x_lo8*w_hi8) * 2^-12       v_mfma_scale_f32_32x32x64_f8f6f4 on e5m2 operands (x_hi8 = e5m2(x_hi)), E8M0
+//                                                    scale 2^-12: twice the cycles of the f16 form for four times the K
+// so a 32-deep k-step of a 32x32 block is 2 f16 MFMAs + 1 scaled MFMA = 4 issue units instead of the 6 of bf16x3, with the
+// loads, LDS images and staging of the bf16x3 kernels unchanged.  Measured per launch against bf16x3 on the same box
+// (profiles/r03_p16_*): forward / bwd-data 1.16-1.19x, weight gradient 1.15x; error against float64 2.1e-5 (bf16x3: 4.5e-6;
+// per-kernel bar 1e-4, tests/test_gpu_conv.py).  Same gather, row spaces, fusions and LDS-staged epilogue as conv.hip.
 //
-// Fragment maps (cdna_hip_programming.md §3): lane l (r = l & 31, h = l >> 5) holds A[row r][k = 8h + j] and
-// B[k = 8h + j][col r], j = 0..7 -> one 16-byte LDS read per operand.  LDS image per operand plane:
-// [4 k-octets][rows][8 bf16], rows of octet o rotated by 2*o so that both the 16-byte stores of the staging
+// Plane format ("P16", same packed geometry as before): hi plane = IEEE halves; lo plane = per element TWO e5m2 bytes,
+// [e5m2(x_hi) | e5m2((x - x_hi) * 2^12) << 8] for gathered operands (activations, gradients) and the two bytes swapped for
+// weights -- so that the two lo-plane fragments a lane reads per 32-deep step (2 x 16 bytes) ARE the 32-byte operands of the
+// scaled MFMA: slot pairs are (x_hi8, w_lo8) and (x_lo8, w_hi8), no byte shuffling in the loop.  value = hi + lo8 * 2^-12
+// (within 2^-15 of x).  Gradients travel scaled by a power of two (pp_grad_scale: halves stop at 6e-8) and the weight
+// gradient divides it out.
+//
+// Fragment maps (cdna_hip_programming.md section 3): lane l (r = l & 31, h = l >> 5) holds A[row r][k = 8h + j] and
+// B[k = 8h + j][col r], j = 0..7 -> one 16-byte LDS read per operand and plane.  LDS image per operand plane:
+// [4 k-octets][rows][8 x 16 bit], rows of octet o rotated by 2*o so that both the 16-byte stores of the staging
 // threads (4 threads per row) and the 512-byte fragment reads are bank-conflict free.
 #include "conv_common.h"
+#include "p16.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));  // (16-byte fragment container of the transposing LDS reads)
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+typedef int intx8 __attribute__((ext_vector_type(8)));
+// E8M0 scales of the scaled MFMA in ONE register: byte 0 (opsel 0) = 115 = 2^-12 for the gathered operand, byte 1 (opsel 1) = 127 = 1
+#define P16_SCALES 0x7f73
 
 __device__ __forceinline__ void split8(const float4& lo4, const float4& hi4, uint4* out_hi, uint4* out_lo) {
   const float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-  bf16x8 h, l;
+  unsigned h[8], u[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const __bf16 hh = (__bf16)v[j];
-    h[j] = hh;
-    l[j] = (__bf16)(v[j] - (float)hh);
+    unsigned h8, l8;
+    p16_encode(v[j], &h[j], &h8, &l8);
+    u[j] = h8 | (l8 << 8);
   }
-  *out_hi = *reinterpret_cast<uint4*>(&h);
-  *out_lo = *reinterpret_cast<uint4*>(&l);
+  *out_hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+  *out_lo = make_uint4(u[0] | (u[1] << 16), u[2] | (u[3] << 16), u[4] | (u[5] << 16), u[6] | (u[7] << 16));
 }
 
-// AP: the gathered operand comes from pre-split bf16 (hi, lo) planes (pp_split_planes_bf16x3, same [rows][ld]
+// AP: the gathered operand comes from pre-split (hi, lo) planes (pp_split_planes_bf16x3, same [rows][ld]
 // geometry as the f32 tensor) instead of being split from f32 while staging: no conversion VALU in the loop.
 __device__ __forceinline__ void split4(const float4& v4, uint2* out_hi, uint2* out_lo) {
   const float v[4] = {v4.x, v4.y, v4.z, v4.w};
-  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-  bf16x4 h, l;
+  unsigned h[4], u[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const __bf16 hh = (__bf16)v[j];
-    h[j] = hh;
-    l[j] = (__bf16)(v[j] - (float)hh);
+    unsigned h8, l8;
+    p16_encode(v[j], &h[j], &h8, &l8);
+    u[j] = h8 | (l8 << 8);
   }
-  *out_hi = *reinterpret_cast<uint2*>(&h);
-  *out_lo = *reinterpret_cast<uint2*>(&l);
+  *out_hi = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+  *out_lo = make_uint2(u[0] | (u[1] << 16), u[2] | (u[3] << 16));
+}
+
+// One 32-deep k-step of a (32 TM) x (32 TN) block set from the rotated LDS images (row_a / row_b: this lane's first tile row of
+// each operand; a_ok: bit a set = row block a is live, else it reads the all-zero slot `a_zero`): cross terms first (their
+// fragments die with them), one row block at a time, then the two f16 half-steps.
+template <int TM, int TN, int BM, int BN>
+__device__ __forceinline__ void mma_step_p16(floatx16 (&acc)[TM][TN], const uint4* Ahi, const uint4* Alo, const uint4* Bhi, const uint4* Blo,
+                                             int row_a, int row_b, int h, unsigned a_ok = ~0u, int a_zero = 0) {
+  {
+    intx8 bq[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int o = 2 * s + h;
+        const uint4 t = Blo[o * BN + ((row_b + b * 32 + 2 * o) & (BN - 1))];
+        bq[b][4 * s] = (int)t.x; bq[b][4 * s + 1] = (int)t.y; bq[b][4 * s + 2] = (int)t.z; bq[b][4 * s + 3] = (int)t.w;
+      }
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      intx8 aq;
+      const bool ok = (a_ok >> a) & 1u;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int o = 2 * s + h;
+        const uint4 t = Alo[ok ? o * BM + ((row_a + a * 32 + 2 * o) & (BM - 1)) : a_zero];
+        aq[4 * s] = (int)t.x; aq[4 * s + 1] = (int)t.y; aq[4 * s + 2] = (int)t.z; aq[4 * s + 3] = (int)t.w;
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq, bq[b], acc[a][b], 1, 1, 0, P16_SCALES, 1, P16_SCALES);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int o = 2 * s + h;
+    halfx8 bh[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      uint4 t = Bhi[o * BN + ((row_b + b * 32 + 2 * o) & (BN - 1))];
+      bh[b] = *reinterpret_cast<halfx8*>(&t);
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const bool ok = (a_ok >> a) & 1u;
+      uint4 t = Ahi[ok ? o * BM + ((row_a + a * 32 + 2 * o) & (BM - 1)) : a_zero];
+      const halfx8 ah = *reinterpret_cast<halfx8*>(&t);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[b], acc[a][b], 0, 0, 0);
+    }
+  }
 }
 
 // ---- the PACKED plane layout ----
-// A tensor [rows][ld] (ld % 8 == 0) stored as bf16 (hi, lo) planes occupies rows * ld * 4 bytes, like float32, cut into 32-byte
-// groups of 8 consecutive channels: bytes 0..15 = the 8 hi values, bytes 16..31 = the 8 lo values (value = hi + lo, within
-// 2^-17 of the float32 that was split).  "hi" points at the buffer, "lo" 16 bytes behind it, and BOTH are addressed with the
+// A tensor [rows][ld] (ld % 8 == 0) stored as (hi, lo) planes occupies rows * ld * 4 bytes, like float32, cut into 32-byte
+// groups of 8 consecutive channels: bytes 0..15 = the 8 hi halves, bytes 16..31 = the 8 lo units (value = hi + lo8 * 2^-12, within
+// 2^-15 of the float32 that was split).  "hi" points at the buffer, "lo" 16 bytes behind it, and BOTH are addressed with the
 // float32 byte offsets of the element's group -- so a staging thread that used to fetch the two float4 of an octet fetches
 // the same 32 contiguous bytes, and 128-byte row segments stay whole (two separate planes cut every access into 64-byte
 // halves and cost 5 % on the forward launches: profiles/r02_planes_separate_vs_packed.txt).
@@ -60,17 +122,15 @@ __device__ __forceinline__ float4 planes_ld4(const void* hi, const void* lo, lon
   const long long q = pk4(i4);
   const uint2 h = reinterpret_cast<const uint2*>(hi)[q], l = reinterpret_cast<const uint2*>(lo)[q];
   float4 v;
-  v.x = __uint_as_float(h.x << 16) + __uint_as_float(l.x << 16);
-  v.y = __uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u);
-  v.z = __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16);
-  v.w = __uint_as_float(h.y & 0xffff0000u) + __uint_as_float(l.y & 0xffff0000u);
+  p16_value2(h.x, l.x, &v.x, &v.y);
+  p16_value2(h.y, l.y, &v.z, &v.w);
   return v;
 }
-// the hi plane alone: enough for the sign / zero test of a ReLU source (bf16 keeps the f32 exponent range)
+// the hi plane alone: enough for the sign / zero test of a ReLU source (+1 / 0 per element)
 __device__ __forceinline__ float4 hi_ld4(const void* hi, long long i4) {
   const uint2 h = reinterpret_cast<const uint2*>(hi)[pk4(i4)];
-  return make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u), __uint_as_float(h.y << 16),
-                     __uint_as_float(h.y & 0xffff0000u));
+  return make_float4(p16_pos(h.x & 0xffffu) ? 1.f : 0.f, p16_pos(h.x >> 16) ? 1.f : 0.f, p16_pos(h.y & 0xffffu) ? 1.f : 0.f,
+                     p16_pos(h.y >> 16) ? 1.f : 0.f);
 }
 __device__ __forceinline__ void planes_st4(void* hi, void* lo, long long i4, const float4& v) {
   uint2 oh, ol;
@@ -204,17 +264,15 @@ __device__ __forceinline__ void epilogue3(const IgemmParams& p, floatx16 (&acc)[
                 const unsigned sx = odd ? q.x : q.z, sy = odd ? q.y : q.w;
                 const unsigned rx = lane_xor1(sx), ry = lane_xor1(sy);
                 const unsigned hx = odd ? rx : q.x, hy = odd ? ry : q.y, lx = odd ? q.z : rx, ly = odd ? q.w : ry;
-                ad[g].x = __uint_as_float(hx << 16) + __uint_as_float(lx << 16);
-                ad[g].y = __uint_as_float(hx & 0xffff0000u) + __uint_as_float(lx & 0xffff0000u);
-                ad[g].z = __uint_as_float(hy << 16) + __uint_as_float(ly << 16);
-                ad[g].w = __uint_as_float(hy & 0xffff0000u) + __uint_as_float(ly & 0xffff0000u);
+                p16_value2(hx, lx, &ad[g].x, &ad[g].y);
+                p16_value2(hy, ly, &ad[g].z, &ad[g].w);
               }
               if (has_mask && mask_pl) {
                 const uint4 q = *reinterpret_cast<const uint4*>(&mk[g]);
                 const unsigned rx = lane_xor1(q.z), ry = lane_xor1(q.w);  // the even lane's second half
                 const unsigned hx = odd ? rx : q.x, hy = odd ? ry : q.y;
-                mk[g] = make_float4(__uint_as_float(hx << 16), __uint_as_float(hx & 0xffff0000u), __uint_as_float(hy << 16),
-                                    __uint_as_float(hy & 0xffff0000u));
+                mk[g] = make_float4(p16_pos(hx & 0xffffu) ? 1.f : 0.f, p16_pos(hx >> 16) ? 1.f : 0.f, p16_pos(hy & 0xffffu) ? 1.f : 0.f,
+                                    p16_pos(hy >> 16) ? 1.f : 0.f);
               }
               if (has_add) { v.x += ad[g].x; v.y += ad[g].y; v.z += ad[g].z; v.w += ad[g].w; }
               if (has_mask) {
@@ -384,35 +442,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
       advance();
       load_step();  // in flight under the MFMAs below
     }
-#pragma unroll
-    for (int s = 0; s < BK / 16; ++s) {
-      const int o = 2 * s + h;
-      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-      for (int a = 0; a < TM; ++a) {
-        const int slot = o * BM + ((wm * 32 * TM + a * 32 + il + 2 * o) & (BM - 1));
-        uint4 t = Ahi[slot];
-        ah[a] = *reinterpret_cast<bf16x8*>(&t);
-        t = Alo[slot];
-        al[a] = *reinterpret_cast<bf16x8*>(&t);
-      }
-#pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        const int slot = o * BN + ((wn * 32 * TN + b * 32 + il + 2 * o) & (BN - 1));
-        uint4 t = Bhi[slot];
-        bh[b] = *reinterpret_cast<bf16x8*>(&t);
-        t = Blo[slot];
-        bl[b] = *reinterpret_cast<bf16x8*>(&t);
-      }
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-        }
-    }
+    mma_step_p16<TM, TN, BM, BN>(acc, Ahi, Alo, Bhi, Blo, wm * 32 * TM + il, wn * 32 * TN + il, h);
     __syncthreads();  // every wave has read this step's tiles
     if (more) {
       store_step();
@@ -618,36 +648,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
     // (left alone the scheduler sinks the loads below the MFMAs, or pulls the conversion of the loaded tile -- and
     // with it the wait for the loads -- up to the first MFMA: pin loads | first half of the MFMAs | rest + conversion)
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < BK / 16; ++s) {
-      const int o = 2 * s + h;
-      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-      for (int a = 0; a < TM; ++a) {
-        const int slot = o * BM + ((wm * 32 * TM + a * 32 + il + 2 * o) & (BM - 1));
-        uint4 t = Ahi[slot];
-        ah[a] = *reinterpret_cast<bf16x8*>(&t);
-        t = Alo[slot];
-        al[a] = *reinterpret_cast<bf16x8*>(&t);
-      }
-#pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        const int slot = o * BN + ((wn * 32 * TN + b * 32 + il + 2 * o) & (BN - 1));
-        uint4 t = Bhi[slot];
-        bh[b] = *reinterpret_cast<bf16x8*>(&t);
-        t = Blo[slot];
-        bl[b] = *reinterpret_cast<bf16x8*>(&t);
-      }
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-        }
-      if (s == 0) __builtin_amdgcn_sched_barrier(0);
-    }
+    mma_step_p16<TM, TN, BM, BN>(acc, Ahi, Alo, Bhi, Blo, wm * 32 * TM + il, wn * 32 * TN + il, h);
     split_step();     // conversion VALU issues while this wave's MFMAs drain
     __syncthreads();  // every wave has read this step's tiles
     store_step();
@@ -877,50 +878,15 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
     unsigned okm[(TM + 1) / 2];
 #pragma unroll
     for (int a = 0; a < (TM + 1) / 2; ++a) okm[a] = f_valid[a] & tap_bits;
+    // (cross terms first, one row block at a time, then the two f16 half-steps: mma_step_p16)
+    unsigned a_ok = 0;
 #pragma unroll
-    for (int s = 0; s < BK / 16; ++s) {
-      const int o = 2 * s + h;
-      // (TM == 4: the gathered fragments are fetched two row blocks at a time, against the same weight fragments -- 16 fewer live
-      // registers, which is what keeps the 256-row tile from spilling)
-      constexpr int AG = TM > 2 ? 2 : TM;
-      bf16x8 bh[TN], bl[TN];
-#pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        const int slot = o * BN + ((wn * 32 * TN + b * 32 + il + 2 * o) & (BN - 1));
-        uint4 t = Bhi[slot];
-        bh[b] = *reinterpret_cast<bf16x8*>(&t);
-        t = Blo[slot];
-        bl[b] = *reinterpret_cast<bf16x8*>(&t);
-      }
-#pragma unroll
-      for (int a0 = 0; a0 < TM; a0 += AG) {
-        bf16x8 ah[AG], al[AG];
-#pragma unroll
-        for (int aa = 0; aa < AG; ++aa) {
-          const int a = a0 + aa;
-          const bool ok = ((okm[a >> 1] >> (16 * (a & 1))) & 0xffffu) != 0;
-          // padded taps read the all-zero slot: one address select per fragment (zeroing the eight fragment registers
-          // instead measured 1 % slower)
-          const int slot = ok ? o * BM + ((wm * 32 * TM + a * 32 + il + dx + 2 * o) & (BM - 1)) : NO * BM;
-          uint4 t = Ahi[slot];
-          ah[aa] = *reinterpret_cast<bf16x8*>(&t);
-          t = Alo[slot];
-          al[aa] = *reinterpret_cast<bf16x8*>(&t);
-        }
-#pragma unroll
-        for (int aa = 0; aa < AG; ++aa)
-#pragma unroll
-          for (int b = 0; b < TN; ++b) {
-            acc[a0 + aa][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[aa], bh[b], acc[a0 + aa][b], 0, 0, 0);
-            acc[a0 + aa][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[aa], bl[b], acc[a0 + aa][b], 0, 0, 0);
-            acc[a0 + aa][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[aa], bh[b], acc[a0 + aa][b], 0, 0, 0);
-          }
-      }
-      // scheduling hint: interleave the LDS fragment reads of this half-step with its MFMAs (measured on the head shapes: +3 %
-      // over a plain barrier between the two halves, +1.7 % in the training step; the same hint makes igemm3f's 256x128 tile
-      // and the large weight-gradient launches 2 % slower, so it stays here only)
-      __builtin_amdgcn_iglp_opt(1);
-    }
+    for (int a = 0; a < TM; ++a) a_ok |= (((okm[a >> 1] >> (16 * (a & 1))) & 0xffffu) != 0 ? 1u : 0u) << a;
+    // padded taps read the all-zero slot: one address select per fragment
+    mma_step_p16<TM, TN, BM, BN>(acc, Ahi, Alo, Bhi, Blo, wm * 32 * TM + il + dx, wn * 32 * TN + il, h, a_ok, NO * BM);
+    // scheduling hint: interleave the LDS fragment reads of this step with its MFMAs (measured on the head shapes with the
+    // bf16x3 body: +3 % over a plain order, +1.7 % in the training step)
+    __builtin_amdgcn_iglp_opt(1);
   };
 
   std::integral_constant<int, 0> t0;
@@ -1081,12 +1047,34 @@ __global__ void rl_splitk_finish_kernel(const IgemmParams p, int splits, const f
 }
 
 // ---- activation / gradient split: f32 [rows][ld] -> bf16 hi/lo planes with the same geometry ----
-__global__ void split_planes_kernel(size_t n8, const float4* __restrict__ src, uint4* __restrict__ hi, uint4* __restrict__ lo) {
+__global__ void split_planes_kernel(size_t n8, const float4* __restrict__ src, uint4* __restrict__ hi, uint4* __restrict__ lo,
+                                    const float* __restrict__ scale) {
+  const float sc = scale ? *scale : 1.f;  // (a power of two: exact)
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
     uint4 h, l;
-    split8(src[2 * i], src[2 * i + 1], &h, &l);
+    float4 a = src[2 * i], b = src[2 * i + 1];
+    a.x *= sc; a.y *= sc; a.z *= sc; a.w *= sc;
+    b.x *= sc; b.y *= sc; b.z *= sc; b.w *= sc;
+    split8(a, b, &h, &l);
     hi[2 * i] = h;  // packed planes: group i = 32 bytes, hi then lo (lo = hi + 16 bytes)
     lo[2 * i] = l;
+  }
+}
+
+// The power of two the gradient chain travels multiplied by (halves stop at 6e-8, loss gradients are ~1e-7): every loss
+// gradient is bounded by ~1 / max(1, positives of its head) (focal: |dL/dlogit| <= 1 / n, orthogonal_l1: <= 0.125 / n), so
+// 2^G = 2^8 * 2^floor(log2(max(1, min positives))) keeps the largest element near 2^8 and leaves 2^8 of headroom for the
+// growth through the backward chain; scale2 = {2^G, 2^-G}.
+__global__ void grad_scale_kernel(const int* __restrict__ counts, int n_counts, float* __restrict__ scale2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int n = 0x7fffffff;
+    for (int i = 0; i < n_counts; ++i) n = counts[i] < n ? counts[i] : n;
+    n = n < 1 ? 1 : n;
+    int e = 0;
+    while ((n >> (e + 1)) != 0) ++e;
+    const float s = __uint_as_float((unsigned)(127 + 8 + e) << 23);
+    scale2[0] = s;
+    scale2[1] = 1.f / s;
   }
 }
 
@@ -1119,7 +1107,7 @@ __global__ void row_block_flags_planes_kernel(const uint2* __restrict__ hi, cons
     const int r = i / cols4, c = i - r * cols4;
     const long long o = pk4((long long)(r0 + r) * ld4 + c);
     const uint2 h = hi[o], l = lo[o];
-    any |= ((h.x | h.y | l.x | l.y) & 0x7fff7fffu) != 0u;
+    any |= (((h.x | h.y) & 0x7fff7fffu) | ((l.x | l.y) & 0x7f7f7f7fu)) != 0u;  // sign bits of the halves / of the e5m2 bytes aside
   }
   any = __syncthreads_or(any);
   if (threadIdx.x == 0) flags[blk] = any ? 1 : 0;
@@ -1182,7 +1170,21 @@ extern "C" int pp_row_block_list_planes_within(pp_ctx* ctx, const void* x_hi, co
   return PP_OK;
 }
 
+static int split_planes_impl(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo, const float* scale);
 extern "C" int pp_split_planes_bf16x3(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo) {
+  return split_planes_impl(ctx, n, src, hi, lo, nullptr);
+}
+extern "C" int pp_split_planes_scaled_bf16x3(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo, const float* scale_dev) {
+  return split_planes_impl(ctx, n, src, hi, lo, scale_dev);
+}
+extern "C" int pp_grad_scale_from_counts(pp_ctx* ctx, const int* counts_dev, int n_counts, float* scale2_dev) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, counts_dev && scale2_dev && n_counts >= 1 && n_counts <= 16, PP_ERR_ARG, "pp_grad_scale_from_counts: bad arguments");
+  hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(64), 0, ctx->stream, counts_dev, n_counts, scale2_dev);
+  PP_CHECK_LAUNCH(ctx, "pp_grad_scale_from_counts");
+  return PP_OK;
+}
+static int split_planes_impl(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo, const float* scale) {
   PP_REQUIRE_CTX(ctx);
   PP_CHECK_ARG(ctx, src && hi && lo && n % 8 == 0, PP_ERR_ARG, "pp_split_planes_bf16x3: n must be a multiple of 8");
   PP_CHECK_ARG(ctx, pp_is_aligned16(src) && pp_is_packed(hi, lo), PP_ERR_ALIGN, "pp_split_planes_bf16x3: alignment / packed planes (lo = hi + 16 bytes)");
@@ -1190,7 +1192,7 @@ extern "C" int pp_split_planes_bf16x3(pp_ctx* ctx, size_t n, const float* src, v
   size_t blocks = (n / 8 + 255) / 256;
   const size_t cap = (size_t)(ctx->n_cu > 0 ? ctx->n_cu : 256) * 8;
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, n / 8, (const float4*)src, (uint4*)hi, (uint4*)lo);
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, n / 8, (const float4*)src, (uint4*)hi, (uint4*)lo, scale);
   PP_CHECK_LAUNCH(ctx, "pp_split_planes_bf16x3");
   return PP_OK;
 }
@@ -1206,9 +1208,9 @@ __device__ __forceinline__ void split_weights_tile(int tap, int ci0, int co0, in
     const int ci = ci0 + j, co = co0 + tx;
     float v = 0.f;
     if (ci < cin && co < cout) v = w[((long long)tap * cin + ci) * ld_w + co];
-    const __bf16 hh = (__bf16)v;
-    const __bf16 ll = (__bf16)(v - (float)hh);
-    const unsigned short uh = *reinterpret_cast<const unsigned short*>(&hh), ul = *reinterpret_cast<const unsigned short*>(&ll);
+    unsigned h16, h8, l8;
+    p16_encode(v, &h16, &h8, &l8);
+    const unsigned short uh = (unsigned short)h16, ul = (unsigned short)(l8 | (h8 << 8));  // the weights' byte order: [rem | hi8 << 8]
     t_hi[j][tx] = uh;
     t_lo[j][tx] = ul;
     if (dg_hi && ci < cin && co < dg_ld) {  // bwd-data layout: [tap][ci][co], co contiguous
@@ -1441,7 +1443,7 @@ static void split_capture_pass(hipStream_t st, const IgemmParams& p, void* chi, 
   const size_t n8 = (size_t)(p.src_rows * (long long)p.ld_src / 8);
   size_t blocks = (n8 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n8, (const float4*)p.src, (uint4*)chi, (uint4*)clo);
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n8, (const float4*)p.src, (uint4*)chi, (uint4*)clo, (const float*)nullptr);
 }
 
 // chi / clo (may be NULL): also write the bf16 split of the gathered f32 operand (pp_ctx_set_split_capture) -- inside the
@@ -1866,6 +1868,7 @@ struct Wgrad3Params {
   int max_wraps;  // ceil(32 / narrowest level width): row wraps one 32-row step can cross
   int sp_min_steps;  // SP: listed 32-row blocks one workgroup should at least reduce (fewer splits when the list is short)
   long long src_rows;
+  const float* inv_scale;  // device scalar 2^-G (NULL: 1): dy travels multiplied by 2^G (pp_ctx_set_grad_scale), dW / dbias leave unscaled
 };
 
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned short* lds, int elem_off0, int elem_off1) {
@@ -1875,6 +1878,64 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned short* lds, int elem_of
   typedef short shortx8 __attribute__((ext_vector_type(8)));
   shortx8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return *reinterpret_cast<bf16x8*>(&v);
+}
+
+// One 32-pixel step of the weight gradient's (32 TM) x (32 TN) blocks from the pixel-major LDS images through the transposing
+// reads: the lo fragments of the two 16-pixel halves are the e5m2 operands of ONE scaled MFMA (a (hi8, lo8) pair travels
+// through ds_read_b64_tr_b16 as one 16-bit unit); both operands are gathered-type tensors, so the units of dy swap their bytes
+// (8 v_perm per column block), then the two f16 half-steps.
+template <int TM, int TN>
+__device__ __forceinline__ void wgrad_step_p16(floatx16 (&acc)[TM][TN], const unsigned short* Xhi, const unsigned short* Xlo,
+                                               const unsigned short* Ghi, const unsigned short* Glo, int PA, int PB, int xcol0, int gcol0,
+                                               int hh, int gq) {
+  {
+    intx8 gq8[TN];
+#pragma unroll
+    for (int c = 0; c < TN; ++c)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int row0 = 16 * s + 8 * hh + gq, col = gcol0 + c * 32;
+        const bf16x8 t = tr_frag(Glo, row0 * PB + col, (row0 + 4) * PB + col);
+        const uint4 u = *reinterpret_cast<const uint4*>(&t);
+        gq8[c][4 * s] = (int)__builtin_amdgcn_perm(u.x, u.x, 0x02030001u);
+        gq8[c][4 * s + 1] = (int)__builtin_amdgcn_perm(u.y, u.y, 0x02030001u);
+        gq8[c][4 * s + 2] = (int)__builtin_amdgcn_perm(u.z, u.z, 0x02030001u);
+        gq8[c][4 * s + 3] = (int)__builtin_amdgcn_perm(u.w, u.w, 0x02030001u);
+      }
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      intx8 xq8;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int row0 = 16 * s + 8 * hh + gq, col = xcol0 + a * 32;
+        const bf16x8 t = tr_frag(Xlo, row0 * PA + col, (row0 + 4) * PA + col);
+        const uint4 u = *reinterpret_cast<const uint4*>(&t);
+        xq8[4 * s] = (int)u.x; xq8[4 * s + 1] = (int)u.y; xq8[4 * s + 2] = (int)u.z; xq8[4 * s + 3] = (int)u.w;
+      }
+#pragma unroll
+      for (int c = 0; c < TN; ++c) acc[a][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xq8, gq8[c], acc[a][c], 1, 1, 0, P16_SCALES, 1, P16_SCALES);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int row0 = 16 * s + 8 * hh + gq;
+    halfx8 gh[TN];
+#pragma unroll
+    for (int c = 0; c < TN; ++c) {
+      const int col = gcol0 + c * 32;
+      const bf16x8 t = tr_frag(Ghi, row0 * PB + col, (row0 + 4) * PB + col);
+      gh[c] = *reinterpret_cast<const halfx8*>(&t);
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const int col = xcol0 + a * 32;
+      const bf16x8 t = tr_frag(Xhi, row0 * PA + col, (row0 + 4) * PA + col);
+      const halfx8 xh = *reinterpret_cast<const halfx8*>(&t);
+#pragma unroll
+      for (int c = 0; c < TN; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, gh[c], acc[a][c], 0, 0, 0);
+    }
+    if (s == 0) __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 // AP: x and dy come from pre-split bf16 planes (16-byte = 8-channel chunks, no conversion in the loop).
@@ -1893,6 +1954,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 2 : 3) void wgrad3_kernel(con
   unsigned short* Glo = Ghi + BK * PB;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float inv_g = p.inv_scale ? *p.inv_scale : 1.f;
   const int wm = wave >> 1, wn = wave & 1;
   int b = xcd_remap((int)blockIdx.x, (int)gridDim.x);
   const int tile_n = b % p.n_tiles_n;
@@ -1984,10 +2046,6 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 2 : 3) void wgrad3_kernel(con
       while (w.y >= w.OH) { w.y -= w.OH; ++w.n; }
     }
   };
-  auto bf2f = [](unsigned int packed, float* lo_elem, float* hi_elem) {
-    *lo_elem = __uint_as_float(packed << 16);
-    *hi_elem = __uint_as_float(packed & 0xffff0000u);
-  };
   auto store_step = [&]() {
     if (AP) {
 #pragma unroll
@@ -2008,13 +2066,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 2 : 3) void wgrad3_kernel(con
             const unsigned int hw[4] = {pbh[j].x, pbh[j].y, pbh[j].z, pbh[j].w}, lw[4] = {pbl[j].x, pbl[j].y, pbl[j].z, pbl[j].w};
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float h0, h1, l0, l1;
-              bf2f(hw[e], &h0, &h1);
-              bf2f(lw[e], &l0, &l1);
-              v[2 * e] = h0 + l0;
-              v[2 * e + 1] = h1 + l1;
-            }
+            for (int e = 0; e < 4; ++e) p16_value2(hw[e], lw[e], &v[2 * e], &v[2 * e + 1]);
             bsum[2 * j].x += v[0]; bsum[2 * j].y += v[1]; bsum[2 * j].z += v[2]; bsum[2 * j].w += v[3];
             bsum[2 * j + 1].x += v[4]; bsum[2 * j + 1].y += v[5]; bsum[2 * j + 1].z += v[6]; bsum[2 * j + 1].w += v[7];
           }
@@ -2062,31 +2114,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 2 : 3) void wgrad3_kernel(con
   for (int step = 0; step < n_steps; ++step) {
     const bool more = step + 1 < n_steps;
     if (more) load_step();
-#pragma unroll
-    for (int s = 0; s < BK / 16; ++s) {
-      const int row0 = 16 * s + 8 * hh + gq;  // pixel row this lane addresses in the first transposed read
-      bf16x8 xh[TM], xl[TM], gh[TN], gl[TN];
-#pragma unroll
-      for (int a = 0; a < TM; ++a) {
-        const int col = wm * 32 * TM + a * 32 + cbase + 4 * gp;
-        xh[a] = tr_frag(Xhi, row0 * PA + col, (row0 + 4) * PA + col);
-        xl[a] = tr_frag(Xlo, row0 * PA + col, (row0 + 4) * PA + col);
-      }
-#pragma unroll
-      for (int c = 0; c < TN; ++c) {
-        const int col = wn * 32 * TN + c * 32 + cbase + 4 * gp;
-        gh[c] = tr_frag(Ghi, row0 * PB + col, (row0 + 4) * PB + col);
-        gl[c] = tr_frag(Glo, row0 * PB + col, (row0 + 4) * PB + col);
-      }
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int c = 0; c < TN; ++c) {
-          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[a], gh[c], acc[a][c], 0, 0, 0);
-          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[a], gl[c], acc[a][c], 0, 0, 0);
-          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[a], gh[c], acc[a][c], 0, 0, 0);
-        }
-    }
+    wgrad_step_p16<TM, TN>(acc, Xhi, Xlo, Ghi, Glo, PA, PB, wm * 32 * TM + cbase + 4 * gp, wn * 32 * TN + cbase + 4 * gp, hh, gq);
     __syncthreads();
     if (more) {
       store_step();
@@ -2103,7 +2131,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 2 : 3) void wgrad3_kernel(con
 #pragma unroll
       for (int c = 0; c < TN; ++c) {
         const int co = n0 + wn * 32 * TN + c * 32 + il;
-        if (co < p.Cout) atomicAdd(dst + co, acc[a][c][r]);
+        if (co < p.Cout) atomicAdd(dst + co, acc[a][c][r] * inv_g);
       }
     }
   }
@@ -2127,7 +2155,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 2 : 3) void wgrad3_kernel(con
       float s = 0.f;
 #pragma unroll 8
       for (int r = 0; r < 32; ++r) s += red[r * BN + tid];
-      if (n0 + tid < p.Cout) atomicAdd(g_dbias + n0 + tid, s);
+      if (n0 + tid < p.Cout) atomicAdd(g_dbias + n0 + tid, s * inv_g);
     }
   }
 }
@@ -2160,6 +2188,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
   unsigned short* Glo = Ghi + BK * PB;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float inv_g = p.inv_scale ? *p.inv_scale : 1.f;
   const int wm = wave >> 1, wn = wave & 1;
   int b = xcd_remap((int)blockIdx.x, (int)gridDim.x);
   const int tile_n = b % p.n_tiles_n;
@@ -2284,10 +2313,6 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
       r_img += wy ? c_SH * c_SW : 0;
     }
   };
-  auto bf2f = [](unsigned int packed, float* lo_elem, float* hi_elem) {
-    *lo_elem = __uint_as_float(packed << 16);
-    *hi_elem = __uint_as_float(packed & 0xffff0000u);
-  };
   auto split_step = [&](auto with_bias) {  // conversion (f32 path) and the bias partial sums: VALU only, under the MFMAs
     constexpr bool WB = decltype(with_bias)::value;
     const float bmask = 1.f;
@@ -2298,13 +2323,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
         const unsigned int hw4[4] = {rb[j].x, rb[j].y, rb[j].z, rb[j].w}, lw4[4] = {rbl[j].x, rbl[j].y, rbl[j].z, rbl[j].w};
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float h0, h1, l0, l1;
-          bf2f(hw4[e], &h0, &h1);
-          bf2f(lw4[e], &l0, &l1);
-          v[2 * e] = h0 + l0;
-          v[2 * e + 1] = h1 + l1;
-        }
+        for (int e = 0; e < 4; ++e) p16_value2(hw4[e], lw4[e], &v[2 * e], &v[2 * e + 1]);
         bsum[2 * j].x = fmaf(v[0], bmask, bsum[2 * j].x); bsum[2 * j].y = fmaf(v[1], bmask, bsum[2 * j].y);
         bsum[2 * j].z = fmaf(v[2], bmask, bsum[2 * j].z); bsum[2 * j].w = fmaf(v[3], bmask, bsum[2 * j].w);
         bsum[2 * j + 1].x = fmaf(v[4], bmask, bsum[2 * j + 1].x); bsum[2 * j + 1].y = fmaf(v[5], bmask, bsum[2 * j + 1].y);
@@ -2368,32 +2387,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
       next_row();
       load_step();  // past the last step m >= m_end: zeros, never stored
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < BK / 16; ++s) {
-        const int row0 = 16 * s + 8 * hh + gq;  // pixel row this lane addresses in the first transposed read
-        bf16x8 xh[TM], xl[TM], gh[TN], gl[TN];
-#pragma unroll
-        for (int a = 0; a < TM; ++a) {
-          const int col = wm * 32 * TM + a * 32 + cbase + 4 * gp;
-          xh[a] = tr_frag(Xhi, row0 * PA + col, (row0 + 4) * PA + col);
-          xl[a] = tr_frag(Xlo, row0 * PA + col, (row0 + 4) * PA + col);
-        }
-#pragma unroll
-        for (int c = 0; c < TN; ++c) {
-          const int col = wn * 32 * TN + c * 32 + cbase + 4 * gp;
-          gh[c] = tr_frag(Ghi, row0 * PB + col, (row0 + 4) * PB + col);
-          gl[c] = tr_frag(Glo, row0 * PB + col, (row0 + 4) * PB + col);
-        }
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int c = 0; c < TN; ++c) {
-            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[a], gh[c], acc[a][c], 0, 0, 0);
-            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[a], gl[c], acc[a][c], 0, 0, 0);
-            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[a], gh[c], acc[a][c], 0, 0, 0);
-          }
-        if (s == 0) __builtin_amdgcn_sched_barrier(0);
-      }
+      wgrad_step_p16<TM, TN>(acc, Xhi, Xlo, Ghi, Glo, PA, PB, wm * 32 * TM + cbase + 4 * gp, wn * 32 * TN + cbase + 4 * gp, hh, gq);
       split_step(with_bias);
       __syncthreads();
       store_step();
@@ -2418,9 +2412,9 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
       for (int c = 0; c < TN; ++c) {
         const int co = n0 + wn * 32 * TN + c * 32 + il;
         if (slice) {
-          if (co < p.ld_w) slice[row + co] = co < p.Cout ? acc[a][c][r] : 0.f;
+          if (co < p.ld_w) slice[row + co] = co < p.Cout ? acc[a][c][r] * inv_g : 0.f;
         } else if (co < p.Cout) {
-          atomicAdd(g_dw + row + co, acc[a][c][r]);
+          atomicAdd(g_dw + row + co, acc[a][c][r] * inv_g);
         }
       }
     }
@@ -2445,9 +2439,9 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
 #pragma unroll 8
       for (int r = 0; r < 32; ++r) s += red[r * BN + tid];
       if (slice) {
-        if (n0 + tid < p.ld_w) slice[ws_slice - p.ld_w + n0 + tid] = n0 + tid < p.Cout ? s : 0.f;  // the bias row closes the slice
+        if (n0 + tid < p.ld_w) slice[ws_slice - p.ld_w + n0 + tid] = n0 + tid < p.Cout ? s * inv_g : 0.f;  // the bias row closes the slice
       } else if (n0 + tid < p.Cout) {
-        atomicAdd(g_dbias + n0 + tid, s);
+        atomicAdd(g_dbias + n0 + tid, s * inv_g);
       }
     }
   }
@@ -2585,6 +2579,7 @@ extern "C" int pp_conv2d_nhwc_bwd_weight_bf16x3(pp_ctx* ctx, const pp_conv_desc*
   p.ld_src = d->ld_x; p.ld_dy = d->ld_y; p.ld_w = d->ld_w;
   p.n_seg = d->in.n_seg;
   fill_segs(ctx, d, true, p.seg, &p.M, &p.src_rows);
+  p.inv_scale = (planes && ctx->grad_scale) ? ctx->grad_scale + 1 : nullptr;  // (f32 operands are never scaled)
   p.Cin = d->cin; p.Cout = d->cout;
   p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
   // (tools/sweep_wgrad.sh: the small 1x1 layers of res4 / res5 take ~35 us for ANY tile / split choice: ~19 latency-bound

@@ -3,7 +3,7 @@
 
 #include "pp_internal.h"
 
-extern "C" const char* pp_version(void) { return "pyrapose_hip 0.4 (gfx950; bf16x3 + f32 MFMA convolutions on packed bf16 planes, sparse 3D-box backward, pose tail, device augmentation)"; }
+extern "C" const char* pp_version(void) { return "pyrapose_hip 0.5 (gfx950; f16c8 (f16 + block-scaled e5m2 MFMA) + f32 MFMA convolutions on packed P16 planes, sparse 3D-box backward, pose tail, device augmentation)"; }
 
 extern "C" int pp_ctx_create(pp_ctx** out, int device, void* hip_stream) {
   if (!out) return PP_ERR_ARG;
@@ -77,6 +77,12 @@ extern "C" int pp_ctx_set_row_block_out(pp_ctx* ctx, const unsigned char* flags,
   PP_CHECK_ARG(ctx, (flags == nullptr) == (list == nullptr), PP_ERR_ARG, "pp_ctx_set_row_block_out: flags and list go together");
   ctx->out_flags = flags;
   ctx->out_list = list;
+  return PP_OK;
+}
+
+extern "C" int pp_ctx_set_grad_scale(pp_ctx* ctx, const float* scale2_dev) {
+  PP_REQUIRE_CTX(ctx);
+  ctx->grad_scale = scale2_dev;  // persistent (NULL: gradients are unscaled)
   return PP_OK;
 }
 

@@ -1,5 +1,6 @@
 // HBM-bound pointwise / resampling kernels of the PyraPose graph (float32, NHWC, 16 B per lane).
 #include "pp_internal.h"
+#include "p16.h"
 
 static inline unsigned grid_for(size_t n_items, int block, pp_ctx* ctx) {
   size_t blocks = (n_items + block - 1) / block;
@@ -192,26 +193,15 @@ __device__ __forceinline__ F8 tv_ld8(const TV& t, size_t i8) {
   F8 v;
   if (t.hi) {
     const uint4 h = reinterpret_cast<const uint4*>(t.hi)[2 * i8], l = reinterpret_cast<const uint4*>(t.hi)[2 * i8 + 1];
-    v.a.x = __uint_as_float(h.x << 16) + __uint_as_float(l.x << 16);
-    v.a.y = __uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u);
-    v.a.z = __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16);
-    v.a.w = __uint_as_float(h.y & 0xffff0000u) + __uint_as_float(l.y & 0xffff0000u);
-    v.b.x = __uint_as_float(h.z << 16) + __uint_as_float(l.z << 16);
-    v.b.y = __uint_as_float(h.z & 0xffff0000u) + __uint_as_float(l.z & 0xffff0000u);
-    v.b.z = __uint_as_float(h.w << 16) + __uint_as_float(l.w << 16);
-    v.b.w = __uint_as_float(h.w & 0xffff0000u) + __uint_as_float(l.w & 0xffff0000u);
+    p16_value2(h.x, l.x, &v.a.x, &v.a.y);
+    p16_value2(h.y, l.y, &v.a.z, &v.a.w);
+    p16_value2(h.z, l.z, &v.b.x, &v.b.y);
+    p16_value2(h.w, l.w, &v.b.z, &v.b.w);
     return v;
   }
   v.a = reinterpret_cast<const float4*>(t.f)[2 * i8];
   v.b = reinterpret_cast<const float4*>(t.f)[2 * i8 + 1];
   return v;
-}
-__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  bf16x2 v;
-  v[0] = (__bf16)a;
-  v[1] = (__bf16)b;
-  return *reinterpret_cast<unsigned*>(&v);
 }
 __device__ __forceinline__ void tv_st8(const TV& t, size_t i8, const F8& v) {
   if (t.f) {
@@ -220,12 +210,16 @@ __device__ __forceinline__ void tv_st8(const TV& t, size_t i8, const F8& v) {
   }
   if (t.hi) {
     const float e[8] = {v.a.x, v.a.y, v.a.z, v.a.w, v.b.x, v.b.y, v.b.z, v.b.w};
-    float r[8];
+    unsigned h[8], u[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = e[j] - (float)(__bf16)e[j];
+    for (int j = 0; j < 8; ++j) {
+      unsigned h8, l8;
+      p16_encode(e[j], &h[j], &h8, &l8);
+      u[j] = h8 | (l8 << 8);
+    }
     uint4* dst = reinterpret_cast<uint4*>(const_cast<void*>(t.hi));
-    dst[2 * i8] = make_uint4(pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]), pack_bf16x2(e[4], e[5]), pack_bf16x2(e[6], e[7]));
-    dst[2 * i8 + 1] = make_uint4(pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3]), pack_bf16x2(r[4], r[5]), pack_bf16x2(r[6], r[7]));
+    dst[2 * i8] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    dst[2 * i8 + 1] = make_uint4(u[0] | (u[1] << 16), u[2] | (u[3] << 16), u[4] | (u[5] << 16), u[6] | (u[7] << 16));
   }
 }
 __device__ __forceinline__ void f8_add(F8& v, const F8& w) {

@@ -24,6 +24,7 @@ struct pp_ctx {
   const unsigned char* skip_flags;
   const unsigned char* out_flags;    // one-shot: the next bf16x3 forward call computes the flagged 32-row output blocks only
   int* out_list;                     //           (pp_ctx_set_row_block_out; list = its scratch)
+  const float* grad_scale;           // device {2^G, 2^-G}: the gradient planes this context's weight gradients read carry the factor 2^G
 };
 
 static inline int pp_fail(pp_ctx* ctx, int code, const char* fmt, ...) {

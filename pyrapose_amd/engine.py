@@ -294,6 +294,15 @@ class Engine(object):
         if self.conv_mode == "bf16x3" and ws_mb > 0:
             for c in self.ctxs:
                 c.set_workspace(ws_mb << 20)
+        # The gradient chain of the plane-stored mode travels multiplied by a power of two (the hi plane holds IEEE halves, which
+        # stop at 6e-8; loss gradients are ~1e-7): {2^G, 2^-G} lives on the device, is refreshed from the positive counts of every
+        # step (pp_grad_scale_from_counts), multiplies the three loss gradients when they are split into planes, rides through
+        # every bwd-data / pointwise launch, and is divided out by the weight-gradient launches (pp_ctx_set_grad_scale).
+        self.gscale = None
+        if self.train and self.po:
+            self.gscale = torch.ones((2,), dtype=torch.float32, device="cuda")
+            for c in self.ctxs:
+                ops.set_grad_scale(c, self.gscale)
         self._lane = 0
         self.trunk_lanes = os.environ.get("PP_TRUNK_LANES", "1") != "0"  # backbone shortcut / FPN level 4-5 chains on lane 1
         # Prefix lane (training with conv1 + res2 frozen, the reference's setting): the frozen prefix is a pure function of
@@ -820,7 +829,7 @@ class Engine(object):
             if self.po and out.ld % 8 == 0:
                 # the loss kernels write float32; the head's last conv takes its dy (bwd-data, bwd-weight) from planes
                 g.pl = _new_planes(out.rows, out.ld)
-                self.bwd_ops.append(Op(lambda gt=gt, pl=g.pl: ops.split_planes3(ctx, gt, pl[0], pl[1]), "pointwise", "split:" + out.name))
+                self.bwd_ops.append(Op(lambda gt=gt, pl=g.pl: ops.split_planes3(ctx, gt, pl[0], pl[1], self.gscale), "pointwise", "split:" + out.name))
             out.contribs.append(("tensor", g))
         for op in reversed(self.graph_ops):
             kind = op["kind"]
@@ -1059,6 +1068,8 @@ class Engine(object):
             ops.count_positives(ctx, self.y_box, self.y_cls, self.y_mask, self.counts)
             if self.grad_sync is not None:
                 self.grad_sync.reduce_counts(self.counts)
+            if self.gscale is not None:
+                ops.grad_scale_from_counts(ctx, self.counts[0:3], self.gscale)
         (bw, bs), (ca, cg), (ma, mg) = self.loss_params["box"], self.loss_params["cls"], self.loss_params["mask"]
         ops.orth_l1(ctx, self.pyr.rowspace(), self.A, self.reg_out.t, self.y_box, bw, bs, self.counts[0:1], 1.0,
                     self.loss_sums[0:1], self.g_reg)

@@ -127,14 +127,37 @@ def planes_ld(planes):
 
 
 def planes_to_f32(planes):
-    """hi + lo as a float32 tensor [rows, ld] (torch arithmetic: tests / inspection)"""
+    """value = hi + lo8 * 2^-12 as a float32 tensor [rows, ld] (torch arithmetic: tests / inspection).  hi = IEEE halves; the lo
+    unit of a gathered-operand tensor is [e5m2(hi) | e5m2(remainder * 2^12) << 8]: its high byte is the remainder."""
     hi, lo = planes
     rows = hi.shape[0]
-    return (hi.contiguous().view(torch.bfloat16).float() + lo.contiguous().view(torch.bfloat16).float()).reshape(rows, -1)
+    rem = (lo.contiguous().to(torch.int32) & 0xff00).to(torch.int16).view(torch.float16).float() / 4096.0
+    return (hi.contiguous().view(torch.float16).float() + rem).reshape(rows, -1)
 
 
-def split_planes3(ctx, src, hi, lo):
-    check(lib.pp_split_planes_bf16x3(ctx.handle, src.numel(), _ptr(src), _ptr(hi), _ptr(lo)), ctx.handle, "pp_split_planes_bf16x3")
+def weight_planes_to_f32(hi, lo):
+    """the same for weight planes (the lo unit's bytes are swapped: the remainder is its LOW byte)"""
+    rem = ((lo.contiguous().to(torch.int32) & 0xff) << 8).to(torch.int16).view(torch.float16).float() / 4096.0
+    return hi.contiguous().view(torch.float16).float() + rem
+
+
+def split_planes3(ctx, src, hi, lo, scale=None):
+    """scale: device float32 [2] = {2^G, 2^-G} (grad_scale_from_counts): the planes hold src * 2^G"""
+    if scale is None:
+        check(lib.pp_split_planes_bf16x3(ctx.handle, src.numel(), _ptr(src), _ptr(hi), _ptr(lo)), ctx.handle, "pp_split_planes_bf16x3")
+    else:
+        check(lib.pp_split_planes_scaled_bf16x3(ctx.handle, src.numel(), _ptr(src), _ptr(hi), _ptr(lo), _ptr(scale)), ctx.handle,
+              "pp_split_planes_scaled_bf16x3")
+
+
+def grad_scale_from_counts(ctx, counts, scale2):
+    check(lib.pp_grad_scale_from_counts(ctx.handle, _ptr(counts), int(counts.numel()), _ptr(scale2)), ctx.handle, "pp_grad_scale_from_counts")
+
+
+def set_grad_scale(ctx, scale2):
+    """persistent: the weight gradients of this context divide the gradient scale out (None: gradients are unscaled)"""
+    ctx._grad_scale_keep = scale2
+    check(lib.pp_ctx_set_grad_scale(ctx.handle, _ptr(scale2)), ctx.handle, "pp_ctx_set_grad_scale")
 
 
 # ---- "f16c8" arithmetic (csrc/conv2.hip): tensors in the H16L8 format, 3 bytes per element ----

@@ -264,11 +264,11 @@ def test_conv_bf16x3_fwd_bwd_data(ctx, case):
     fh, fl = torch.zeros((taps, cout, cin), **u16), torch.zeros((taps, cout, cin), **u16)
     dh, dl = torch.zeros((taps, cin, cout), **u16), torch.zeros((taps, cin, cout), **u16)
     ops.conv_split_weights3(ctx, d, wd, fh, fl, dh, dl)
-    # the planes reproduce the weights to ~2^-17
-    back = (fh.view(torch.bfloat16).float() + fl.view(torch.bfloat16).float()).permute(0, 2, 1).reshape(taps * cin, cout).cpu().numpy()
-    assert rel_err(back, w.reshape(-1, cout)) < 2e-5
-    back = (dh.view(torch.bfloat16).float() + dl.view(torch.bfloat16).float()).reshape(taps * cin, cout).cpu().numpy()
-    assert rel_err(back, w.reshape(-1, cout)) < 2e-5
+    # the planes reproduce the weights to 2^-15 (half + e5m2 remainder)
+    back = ops.weight_planes_to_f32(fh, fl).permute(0, 2, 1).reshape(taps * cin, cout).cpu().numpy()
+    assert rel_err(back, w.reshape(-1, cout)) < 3.1e-5
+    back = ops.weight_planes_to_f32(dh, dl).reshape(taps * cin, cout).cpu().numpy()
+    assert rel_err(back, w.reshape(-1, cout)) < 3.1e-5
     rows_out = sum(B * h * ww for h, ww in out_shapes)
     rng = np.random.default_rng(1)
     res = [torch.as_tensor(rng.standard_normal(tuple(r.shape)), dtype=torch.float64) for r in ref]
@@ -283,7 +283,7 @@ def test_conv_bf16x3_fwd_bwd_data(ctx, case):
     # kernel (tap order), so equal up to f32 summation order
     xh, xl = ops.new_planes(x.shape[0], x.shape[1])
     ops.split_planes3(ctx, x, xh, xl)
-    assert rel_err(ops.planes_to_f32((xh, xl)).cpu().numpy(), x.cpu().numpy()) < 2e-5
+    assert rel_err(ops.planes_to_f32((xh, xl)).cpu().numpy(), x.cpu().numpy()) < 3.1e-5
     y2 = torch.full_like(y, float("nan"))
     yh, yl = ops.new_planes(y.shape[0], y.shape[1])
     ops.conv_fwd3(ctx, d, None, fh, fl, bd.cuda(), _cat_rows(res, ld_y), True, y2, x_planes=(xh, xl), y_planes=(yh, yl))

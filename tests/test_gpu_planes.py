@@ -2,7 +2,7 @@
 every kernel variant that reads or writes planes -- gathered operand, output tile, residual / addend / ReLU source of the
 epilogues, split-K finish, stride-2 parity classes, row-list sparse backward, weight gradient over a block list, the
 pointwise ops on tensor views -- against the SAME launch on float32 tensors.  The products are identical (same hi, lo);
-a value read back from planes is within 2^-17 of the float32 it was split from, so results agree to ~1e-5 of the tensor's
+a value read back from planes is within 2^-15 of the float32 it was split from, so results agree to ~3e-5 of the tensor's
 magnitude; where no operand is read back from planes they agree to f32 summation order."""
 import numpy as np
 import pytest
@@ -91,7 +91,7 @@ def test_planes_only_fwd_and_bwd_data(ctx, case):
     ops.conv_fwd3(ctx, d, None, fh, fl, bd, None, True, None, x_planes=xp, y_planes=yp, res_planes=rp)
     got = merged(yp)[:, :cout]
     scale = float(y[:, :cout].abs().max())
-    assert float((got - y[:, :cout]).abs().max()) <= 2e-5 * scale
+    assert float((got - y[:, :cout]).abs().max()) <= 4e-5 * scale
     # the residual given as f32, output as planes only: exactly the split of the f32 output of the same kernel
     yp2 = nan_planes(y)
     y2 = torch.full_like(y, float("nan"))
@@ -114,14 +114,14 @@ def test_planes_only_fwd_and_bwd_data(ctx, case):
     ops.conv_bwd_data3(ctx, d, None, dh, dl, None, None, None, dy_planes=gp, dx_planes=dxp, addend_planes=ap, relu_src_hi=mp[0])
     got = merged(dxp)
     scale = float(dx.abs().max())
-    assert float((got - dx).abs().max()) <= 2e-5 * scale
+    assert float((got - dx).abs().max()) <= 4e-5 * scale
     assert torch.equal(got == 0, dx == 0) or float(((got == 0) != (dx == 0)).float().mean()) < 1e-4  # the same ReLU mask
     # without addend / mask
     dx0 = torch.full_like(x, float("nan"))
     ops.conv_bwd_data3(ctx, d, gy, dh, dl, None, None, dx0)
     dxp0 = nan_planes(dx)
     ops.conv_bwd_data3(ctx, d, None, dh, dl, None, None, None, dy_planes=gp, dx_planes=dxp0)
-    assert float((merged(dxp0) - dx0).abs().max()) <= 2e-5 * max(float(dx0.abs().max()), 1e-30)
+    assert float((merged(dxp0) - dx0).abs().max()) <= 4e-5 * max(float(dx0.abs().max()), 1e-30)
 
 
 @pytest.mark.parametrize("splits", [3])
@@ -163,8 +163,8 @@ def test_planes_only_split_k(ctx, splits, monkeypatch):
         assert torch.equal(y2, y3) and torch.equal(dx2, dx3)  # deterministic
     finally:
         ctx.set_workspace(0)
-    assert float((y2 - y1).abs().max()) <= 2e-5 * float(y1.abs().max())
-    assert float((dx2 - dx1).abs().max()) <= 2e-5 * float(dx1.abs().max())
+    assert float((y2 - y1).abs().max()) <= 4e-5 * float(y1.abs().max())
+    assert float((dx2 - dx1).abs().max()) <= 4e-5 * float(dx1.abs().max())
     assert bool(y1.isfinite().all()) and bool(dx1.isfinite().all()) and float(y1.abs().max()) > 0
 
 
@@ -199,14 +199,14 @@ def test_planes_only_row_block_skip(ctx, frac):
     dxp = nan_planes(dx0)
     ops.conv_bwd_data3(ctx, d, None, dh, dl, None, None, None, dy_planes=gp, dx_planes=dxp, dy_skip=(f2, b2), addend_planes=ap,
                        relu_src_hi=mp[0])
-    assert float((merged(dxp) - dx0).abs().max()) <= 2e-5 * float(dx0.abs().max())
+    assert float((merged(dxp) - dx0).abs().max()) <= 4e-5 * float(dx0.abs().max())
     assert not bool(f2[nb: 2 * nb].all())  # some blocks were filled, not computed
     # in place on the addend (no ReLU mask): the rows no non-zero reaches are not touched at all, the others get the same sum
     dx1 = torch.full((rows, cin), float("nan"), device="cuda")
     ops.conv_bwd_data3(ctx, d, dy, dh, dl, add, None, dx1)
     acc = split(ctx, add)
     ops.conv_bwd_data3(ctx, d, None, dh, dl, None, None, None, dy_planes=gp, dx_planes=acc, dy_skip=(f2, b2), addend_planes=acc)
-    assert float((merged(acc) - dx1).abs().max()) <= 2e-5 * float(dx1.abs().max())
+    assert float((merged(acc) - dx1).abs().max()) <= 7e-5 * float(dx1.abs().max())  # (the sum is rounded to the plane format twice)
     # without an addend the result is zero outside the blocks the launch flagged in the second half of its scratch: a scan
     # restricted to those blocks (pp_row_block_list_planes_within) finds what the full scan finds
     dxz = nan_planes(dx0)
@@ -233,7 +233,7 @@ def test_planes_only_row_block_skip(ctx, frac):
     ops.conv_bwd_weight3(ctx, d, None, None, dw1, db1, x_planes=xp, dy_planes=gp, dy_skip=(f2, b2))
     scale = max(float(dw0.abs().max()), 1e-30)
     assert float((dw0 - dw1).abs().max()) <= 2e-6 * scale
-    assert float((db0 - db1).abs().max()) <= 2e-5 * max(float(db0.abs().max()), 1e-30)
+    assert float((db0 - db1).abs().max()) <= 4e-5 * max(float(db0.abs().max()), 1e-30)
     if frac == 0.0:
         assert not dw1.any() and not db1.any()
 
@@ -281,11 +281,11 @@ def test_row_list_bwd_data_split_k(ctx, in_place):
                 got = merged(dxp)
             torch.cuda.synchronize()
             assert 0 < int(f2[nb: 2 * nb].sum()) < nb  # the listed launch ran, and not over everything
-            assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max()), ws_mb
+            assert float((got - want).abs().max()) <= 4e-5 * float(want.abs().max()), ws_mb
             outs.append(got)
         finally:
             ctx.set_workspace(0)
-    assert float((outs[0] - outs[1]).abs().max()) <= 1e-5 * float(want.abs().max())  # (two partial sums instead of one; planes hold 2^-17)
+    assert float((outs[0] - outs[1]).abs().max()) <= 4e-5 * float(want.abs().max())  # (two partial sums instead of one; planes hold 2^-15)
 
 
 def test_pointwise_ops_on_views(ctx):
@@ -301,7 +301,7 @@ def test_pointwise_ops_on_views(ctx):
         outp = nan_planes(oth)
         outf = torch.empty_like(oth)
         ops.upsample_add_fwd_v(ctx, B, sh, sw, th, tw, C, ops.tview(None, sp), ops.tview(None, op_), ops.tview(outf, outp))
-        assert float((outf - want).abs().max()) <= 2e-5 * float(want.abs().max())
+        assert float((outf - want).abs().max()) <= 4e-5 * float(want.abs().max())
         wh, wl = split(ctx, outf)
         assert torch.equal(outp[0], wh) and torch.equal(outp[1], wl)  # both output formats hold the same values
         g = torch.as_tensor(rng.standard_normal((B * th * tw, C)), dtype=torch.float32).cuda()
@@ -309,12 +309,12 @@ def test_pointwise_ops_on_views(ctx):
         ops.upsample_add_bwd(ctx, B, sh, sw, th, tw, C, g, None, gs_want)
         gsp = nan_planes(src)
         ops.upsample_add_bwd_v(ctx, B, sh, sw, th, tw, C, ops.tview(None, split(ctx, g)), None, ops.tview(None, gsp))
-        assert float((merged(gsp) - gs_want).abs().max()) <= 2e-5 * float(gs_want.abs().max())
+        assert float((merged(gsp) - gs_want).abs().max()) <= 4e-5 * float(gs_want.abs().max())
     a = torch.as_tensor(rng.standard_normal((1000, 8)), dtype=torch.float32).cuda()
     b = torch.as_tensor(rng.standard_normal((1000, 8)), dtype=torch.float32).cuda()
     outp = nan_planes(a)
     ops.add_n_v(ctx, ops.tview(a), ops.tview(None, split(ctx, b)), None, ops.tview(None, outp))
-    assert float((merged(outp) - (a + b)).abs().max()) <= 2e-5 * float((a + b).abs().max())
+    assert float((merged(outp) - (a + b)).abs().max()) <= 4e-5 * float((a + b).abs().max())
     out = torch.empty_like(a)
     ops.add_n_v(ctx, ops.tview(a), ops.tview(b), ops.tview(a), ops.tview(out))
     assert torch.equal(out, (a + b) + a)
@@ -334,7 +334,7 @@ def test_pointwise_ops_on_views(ctx):
 @pytest.mark.parametrize("mode", ["1", "0"])
 def test_engine_planes_mode_matches_f32_storage(ctx, mode, monkeypatch):
     """The whole training step with planes-only storage (default) vs float32 storage with in-loop splits (PP_PLANES=0): same
-    products; residual / addend reads differ by 2^-17 -> every output and the gradient agree to ~1e-5."""
+    products; residual / addend reads differ by 2^-15 -> every output agrees to ~1e-4."""
     from pyrapose_amd import arch
     from pyrapose_amd.engine import Engine
     from tests.test_gpu_model import random_targets, synth_input
@@ -359,11 +359,11 @@ def test_engine_planes_mode_matches_f32_storage(ctx, mode, monkeypatch):
     if len(store) == 2:
         a, b = store["1"], store["0"]
         for i in range(3):
-            assert float((a[i] - b[i]).abs().max()) <= 3e-5 * float(b[i].abs().max()), i
+            assert float((a[i] - b[i]).abs().max()) <= 2e-4 * float(b[i].abs().max()), i  # (2^-15 per stored tensor, ~60 layers)
         ga, gb = a[3].double(), b[3].double()
         assert float((ga - gb).norm() / gb.norm()) < 5e-2  # (a ReLU input that is zero to rounding may flip between the modes)
         for k in ("3Dbox", "cls", "mask"):
-            assert abs(a[4][k] - b[4][k]) <= 2e-5 * abs(b[4][k])
+            assert abs(a[4][k] - b[4][k]) <= 4e-5 * abs(b[4][k])
 
 
 @pytest.mark.parametrize("case", [c for c in WG3_CASES if c[0] in ("head3x3_multilevel", "head_out_cout117", "lat1x1", "down3x3s2_odd", "x_five_levels")],
@@ -404,6 +404,6 @@ def test_weight_gradient_slices_are_deterministic_and_match_atomics(ctx, case, m
     assert torch.equal(s_dw, s_dw2) and torch.equal(s_db, s_db2)
     scale = float((a_dw - base).abs().max())
     assert float((s_dw - a_dw).abs().max()) <= 2e-6 * scale and float((f_dw - a_dw).abs().max()) <= 2e-6 * scale
-    assert float((s_db - a_db).abs().max()) <= 2e-5 * max(float((a_db - 1).abs().max()), 1e-30)
+    assert float((s_db - a_db).abs().max()) <= 4e-5 * max(float((a_db - 1).abs().max()), 1e-30)
     assert bool(s_dw.isfinite().all()) and float((s_dw - base).abs().max()) > 0
     assert torch.equal(s_dw[:, cout:], base[:, cout:])   # padding columns: + 0
