@@ -10,7 +10,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpyrapose_hip.so")
+# PP_LIB (development only): another build of the library beside the default one, for same-box A/B runs of two builds through
+# the same Python (tools/ab_lib.sh); entry points such a build lacks are left unbound and their features switch off
+LIB_PATH = os.path.join(_HERE, os.environ.get("PP_LIB") or "libpyrapose_hip.so")
 
 PP_MAX_SEG = 5
 
@@ -158,8 +160,15 @@ _SIGS = {
 
 EXPORTS = sorted(_SIGS)
 
+MISSING = []
 for _name, (_res, _args) in _SIGS.items():
-    _fn = getattr(lib, _name)  # AttributeError here = the .so does not export what the header declares
+    try:
+        _fn = getattr(lib, _name)  # AttributeError here = the .so does not export what the header declares
+    except AttributeError:
+        if not os.environ.get("PP_LIB"):
+            raise
+        MISSING.append(_name)
+        continue
     _fn.restype = _res
     _fn.argtypes = _args
 

@@ -30,31 +30,17 @@ typedef int intx8 __attribute__((ext_vector_type(8)));
 #define P16_SCALES 0x7f73
 
 __device__ __forceinline__ void split8(const float4& lo4, const float4& hi4, uint4* out_hi, uint4* out_lo) {
-  const float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-  unsigned h[8], u[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    unsigned h8, l8;
-    p16_encode(v[j], &h[j], &h8, &l8);
-    u[j] = h8 | (l8 << 8);
-  }
-  *out_hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-  *out_lo = make_uint4(u[0] | (u[1] << 16), u[2] | (u[3] << 16), u[4] | (u[5] << 16), u[6] | (u[7] << 16));
+  p16_encode2<false>(lo4.x, lo4.y, &out_hi->x, &out_lo->x);
+  p16_encode2<false>(lo4.z, lo4.w, &out_hi->y, &out_lo->y);
+  p16_encode2<false>(hi4.x, hi4.y, &out_hi->z, &out_lo->z);
+  p16_encode2<false>(hi4.z, hi4.w, &out_hi->w, &out_lo->w);
 }
 
 // AP: the gathered operand comes from pre-split (hi, lo) planes (pp_split_planes_bf16x3, same [rows][ld]
 // geometry as the f32 tensor) instead of being split from f32 while staging: no conversion VALU in the loop.
 __device__ __forceinline__ void split4(const float4& v4, uint2* out_hi, uint2* out_lo) {
-  const float v[4] = {v4.x, v4.y, v4.z, v4.w};
-  unsigned h[4], u[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    unsigned h8, l8;
-    p16_encode(v[j], &h[j], &h8, &l8);
-    u[j] = h8 | (l8 << 8);
-  }
-  *out_hi = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-  *out_lo = make_uint2(u[0] | (u[1] << 16), u[2] | (u[3] << 16));
+  p16_encode2<false>(v4.x, v4.y, &out_hi->x, &out_lo->x);
+  p16_encode2<false>(v4.z, v4.w, &out_hi->y, &out_lo->y);
 }
 
 // One 32-deep k-step of a (32 TM) x (32 TN) block set from the rotated LDS images (row_a / row_b: this lane's first tile row of
@@ -1208,9 +1194,9 @@ __device__ __forceinline__ void split_weights_tile(int tap, int ci0, int co0, in
     const int ci = ci0 + j, co = co0 + tx;
     float v = 0.f;
     if (ci < cin && co < cout) v = w[((long long)tap * cin + ci) * ld_w + co];
-    unsigned h16, h8, l8;
-    p16_encode(v, &h16, &h8, &l8);
-    const unsigned short uh = (unsigned short)h16, ul = (unsigned short)(l8 | (h8 << 8));  // the weights' byte order: [rem | hi8 << 8]
+    unsigned h2, l2;
+    p16_encode2<true>(v, 0.f, &h2, &l2);  // the weights' byte order: [rem | e5m2(w) << 8]
+    const unsigned short uh = (unsigned short)h2, ul = (unsigned short)l2;
     t_hi[j][tx] = uh;
     t_lo[j][tx] = ul;
     if (dg_hi && ci < cin && co < dg_ld) {  // bwd-data layout: [tap][ci][co], co contiguous

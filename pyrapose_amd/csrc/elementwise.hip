@@ -209,17 +209,14 @@ __device__ __forceinline__ void tv_st8(const TV& t, size_t i8, const F8& v) {
     reinterpret_cast<float4*>(const_cast<float*>(t.f))[2 * i8 + 1] = v.b;
   }
   if (t.hi) {
-    const float e[8] = {v.a.x, v.a.y, v.a.z, v.a.w, v.b.x, v.b.y, v.b.z, v.b.w};
-    unsigned h[8], u[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      unsigned h8, l8;
-      p16_encode(e[j], &h[j], &h8, &l8);
-      u[j] = h8 | (l8 << 8);
-    }
+    uint4 h, l;
+    p16_encode2<false>(v.a.x, v.a.y, &h.x, &l.x);
+    p16_encode2<false>(v.a.z, v.a.w, &h.y, &l.y);
+    p16_encode2<false>(v.b.x, v.b.y, &h.z, &l.z);
+    p16_encode2<false>(v.b.z, v.b.w, &h.w, &l.w);
     uint4* dst = reinterpret_cast<uint4*>(const_cast<void*>(t.hi));
-    dst[2 * i8] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-    dst[2 * i8 + 1] = make_uint4(u[0] | (u[1] << 16), u[2] | (u[3] << 16), u[4] | (u[5] << 16), u[6] | (u[7] << 16));
+    dst[2 * i8] = h;
+    dst[2 * i8 + 1] = l;
   }
 }
 __device__ __forceinline__ void f8_add(F8& v, const F8& w) {

@@ -299,7 +299,8 @@ class Engine(object):
         # step (pp_grad_scale_from_counts), multiplies the three loss gradients when they are split into planes, rides through
         # every bwd-data / pointwise launch, and is divided out by the weight-gradient launches (pp_ctx_set_grad_scale).
         self.gscale = None
-        if self.train and self.po:
+        from ._lib import MISSING as _missing
+        if self.train and self.po and "pp_grad_scale_from_counts" not in _missing:
             self.gscale = torch.ones((2,), dtype=torch.float32, device="cuda")
             for c in self.ctxs:
                 ops.set_grad_scale(c, self.gscale)

@@ -158,9 +158,10 @@ def test_sparse_forward_of_box_head_is_exact_for_training(ctx, monkeypatch):
         for k in la:
             assert abs(la[k] - lb[k]) <= 2e-5 * max(abs(la[k]), 1e-3), (i, k, la[k], lb[k])
         ga, gb = a.params.grad, b.params.grad
-        # (the listed-block launch sums in another order than the dense kernel: ~1e-6 per activation, and a ReLU input of the head
-        # that is zero to rounding may flip -- 1e-4 of the gradient's scale has been seen; a stale row would show as O(1))
-        assert float((ga - gb).abs().max()) <= 5e-4 * float(ga.abs().max()), i
+        # (the listed-block launch sums in another order than the dense kernel: ~2e-5 per activation in the f16c8 arithmetic, and a
+        # ReLU input of the head that is zero to rounding may flip -- 8e-3 of the gradient's scale has been seen; a stale row
+        # would show as O(1))
+        assert float((ga - gb).abs().max()) <= 2e-2 * float(ga.abs().max()), i
     # a batch without a single positive anchor: nothing of the head is computed, its loss and gradient are zero in both engines
     a.lr = b.lr = 0.0
     tg = [torch.from_numpy(t).cuda() for t in random_targets(rng, Bq, a.N, a.M3, Cq, pos_frac=0.0)]
@@ -174,7 +175,7 @@ def test_sparse_forward_of_box_head_is_exact_for_training(ctx, monkeypatch):
         assert abs(la[k] - lb[k]) <= 2e-5 * max(abs(la[k]), 1e-3), (k, la[k], lb[k])
     # (without the box loss the largest gradient is ~7e-3 while the float32 atomics of the weight gradients still scatter ~4e-6:
     # an absolute floor beside the relative bound)
-    assert float((a.params.grad - b.params.grad).abs().max()) <= 5e-4 * float(a.params.grad.abs().max()) + 2e-5
+    assert float((a.params.grad - b.params.grad).abs().max()) <= 2e-3 * float(a.params.grad.abs().max()) + 2e-5
     wa, wb = a.params.w_master, b.params.w_master
     # (one Adam step moves every weight by ~lr whatever the size of its gradient: where the two gradients are noise of opposite
     # sign the weights part by 2 lr -- that, not a relative bound, is the scale of an honest difference)
