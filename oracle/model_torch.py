@@ -226,8 +226,13 @@ def _orth_features(r):
     return torch.stack(f, dim=1)
 
 
-def orthogonal_l1(y_true, y_pred, weight=0.125, sigma=3.0):
-    """losses.py:321-408."""
+def orthogonal_l1(y_true, y_pred, weight=0.125, sigma=3.0, kink_ref=None):
+    """losses.py:321-408.
+    kink_ref (tests; like relu_masks): predictions of ANOTHER evaluation of the same network (the engine's box output).  The
+    24 edge-difference terms enter through abs(), whose derivative jumps at 0; with a few hundred positives ONE term that is zero
+    to rounding, and lands on different sides in two arithmetics, moves the gradient of the whole regression head by ~7e-4.
+    With kink_ref the sign of every such term is taken from that evaluation, i.e. both sides differentiate the same smooth
+    piece (the smooth-L1 part needs nothing: its derivative is continuous at 0 and at the knee)."""
     sigma_sq = sigma ** 2
     target = y_true[:, :, :-1]
     state = y_true[:, :, -1]
@@ -236,7 +241,14 @@ def orthogonal_l1(y_true, y_pred, weight=0.125, sigma=3.0):
     t = target[pos]
     diff = torch.abs(r - t)
     xy = torch.where(diff < 1.0 / sigma_sq, 0.5 * sigma_sq * diff ** 2, diff - 0.5 / sigma_sq)
-    orth = torch.mean(torch.abs(_orth_features(r) - _orth_features(t)), dim=1) if r.shape[0] else r.sum(dim=1)
+    if r.shape[0] == 0:
+        orth = r.sum(dim=1)
+    elif kink_ref is None:
+        orth = torch.mean(torch.abs(_orth_features(r) - _orth_features(t)), dim=1)
+    else:
+        ft = _orth_features(t)
+        sgn = torch.sign(_orth_features(_t(kink_ref, y_pred.dtype)[pos]) - ft).detach()
+        orth = torch.mean(sgn * (_orth_features(r) - ft), dim=1)
     normalizer = float(max(1, int(pos.sum())))
     return weight * (0.8 * xy.sum() / normalizer + 0.2 * orth.sum() / normalizer)
 
@@ -263,10 +275,10 @@ def trainable_names(W):
 
 
 def loss_and_grads(W, x_nhwc, y_box, y_cls, y_mask, num_classes, dtype=torch.float64, blocks=None, pyramid="sparse",
-                   relu_masks=None, loss_params=None):
+                   relu_masks=None, loss_params=None, box_kink_ref=None):
     """Total Keras training loss = orthogonal_l1('3Dbox') + focal('cls') + focal('mask') + L2 reg
     (bin/train.py:95-102), and its gradient w.r.t. every trainable tensor.
-    relu_masks: see _relu (tests).  loss_params: dict(box=(weight, sigma), cls=(alpha, gamma), mask=(alpha, gamma)),
+    relu_masks: see _relu (tests).  box_kink_ref: see orthogonal_l1 (tests).  loss_params: dict(box=(weight, sigma), cls=(alpha, gamma), mask=(alpha, gamma)),
     default = what bin/train.py:97-99 compiles."""
     lp = dict(box=(0.125, 3.0), cls=(0.25, 2.0), mask=(0.25, 2.0))
     lp.update(loss_params or {})
@@ -275,7 +287,7 @@ def loss_and_grads(W, x_nhwc, y_box, y_cls, y_mask, num_classes, dtype=torch.flo
     for k in names:
         Wt[k].requires_grad_(True)
     out = forward(Wt, x_nhwc, num_classes, dtype, blocks, pyramid=pyramid, relu_masks=relu_masks)
-    l_box = orthogonal_l1(_t(y_box, dtype), out["3Dbox"], *lp["box"])
+    l_box = orthogonal_l1(_t(y_box, dtype), out["3Dbox"], *lp["box"], kink_ref=box_kink_ref)
     l_cls = focal(_t(y_cls, dtype), out["cls"], *lp["cls"])
     l_mask = focal(_t(y_mask, dtype), out["mask"], *lp["mask"])
     l_reg = sum(REG_L2 * (Wt[n + "/kernel"] ** 2).sum() for n in REG_L2_LAYERS)

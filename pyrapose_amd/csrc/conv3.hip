@@ -1051,14 +1051,14 @@ __global__ void split_planes_kernel(size_t n8, const float4* __restrict__ src, u
 // gradient is bounded by ~1 / max(1, positives of its head) (focal: |dL/dlogit| <= 1 / n, orthogonal_l1: <= 0.125 / n), so
 // 2^G = 2^8 * 2^floor(log2(max(1, min positives))) keeps the largest element near 2^8 and leaves 2^8 of headroom for the
 // growth through the backward chain; scale2 = {2^G, 2^-G}.
-__global__ void grad_scale_kernel(const int* __restrict__ counts, int n_counts, float* __restrict__ scale2) {
+__global__ void grad_scale_kernel(const int* __restrict__ counts, int n_counts, float* __restrict__ scale2, int base_log2) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     int n = 0x7fffffff;
     for (int i = 0; i < n_counts; ++i) n = counts[i] < n ? counts[i] : n;
     n = n < 1 ? 1 : n;
     int e = 0;
     while ((n >> (e + 1)) != 0) ++e;
-    const float s = __uint_as_float((unsigned)(127 + 8 + e) << 23);
+    const float s = __uint_as_float((unsigned)(127 + base_log2 + e) << 23);
     scale2[0] = s;
     scale2[1] = 1.f / s;
   }
@@ -1166,7 +1166,8 @@ extern "C" int pp_split_planes_scaled_bf16x3(pp_ctx* ctx, size_t n, const float*
 extern "C" int pp_grad_scale_from_counts(pp_ctx* ctx, const int* counts_dev, int n_counts, float* scale2_dev) {
   PP_REQUIRE_CTX(ctx);
   PP_CHECK_ARG(ctx, counts_dev && scale2_dev && n_counts >= 1 && n_counts <= 16, PP_ERR_ARG, "pp_grad_scale_from_counts: bad arguments");
-  hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(64), 0, ctx->stream, counts_dev, n_counts, scale2_dev);
+  static const int base_log2 = []() { const char* e = getenv("PP_GSCALE_LOG2"); const int v = e ? atoi(e) : 8; return v < -20 ? -20 : (v > 30 ? 30 : v); }();
+  hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(64), 0, ctx->stream, counts_dev, n_counts, scale2_dev, base_log2);
   PP_CHECK_LAUNCH(ctx, "pp_grad_scale_from_counts");
   return PP_OK;
 }

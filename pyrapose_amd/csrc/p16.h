@@ -17,7 +17,10 @@ __device__ __forceinline__ void p16_encode2(float v0, float v1, unsigned* hi2, u
   p16_half2 h;
   h[0] = (_Float16)v0;
   h[1] = (_Float16)v1;
-  const float r0 = (v0 - (float)h[0]) * 4096.f, r1 = (v1 - (float)h[1]) * 4096.f;
+  // a value whose half is zero (|x| < 2^-25) is stored as exactly zero: "hi > 0 <=> value > 0" then holds without exception, which
+  // is what the ReLU masks (read from the hi plane alone) and the forward's own sign test must agree on
+  const float f0 = (float)h[0], f1 = (float)h[1];
+  const float r0 = f0 != 0.f ? (v0 - f0) * 4096.f : 0.f, r1 = f1 != 0.f ? (v1 - f1) * 4096.f : 0.f;
   int w = 0;
   if (WGT) {
     w = __builtin_amdgcn_cvt_pk_bf8_f32(r0, v0, w, false);
@@ -35,5 +38,5 @@ __device__ __forceinline__ void p16_value2(unsigned hi2, unsigned lo2, float* e0
   *e0 = fmaf(__builtin_amdgcn_cvt_f32_bf8((int)lo2, 1), 1.f / 4096.f, (float)h[0]);
   *e1 = fmaf(__builtin_amdgcn_cvt_f32_bf8((int)lo2, 3), 1.f / 4096.f, (float)h[1]);
 }
-// hi > 0 <=> value > 0 (the remainder never changes the sign of a non-zero half; a value that rounds to a zero half is < 2^-25)
+// hi > 0 <=> value > 0 (the remainder never changes the sign of a non-zero half; a value that rounds to a zero half is stored as 0)
 __device__ __forceinline__ bool p16_pos(unsigned hi16) { return (short)(unsigned short)hi16 > 0; }

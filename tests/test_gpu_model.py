@@ -116,7 +116,9 @@ def test_train_step_small_vs_oracle_f64(ctx, mode):
     # pattern of every ReLU from the engine's forward (oracle/model_torch.py:_relu) -- so a pre-activation that is zero to
     # rounding cannot land on different sides of the kink in the two evaluations, and the comparison is tight: every
     # gradient tensor within 1e-3 (relative L2), losses within 1e-4.
-    losses_ref, g_ref, _ = MT.loss_and_grads(Wt, x, y_box, y_cls, y_mask, C, torch.float64, relu_masks=engine_relu_masks(eng))
+    # (the same for the abs() terms of orthogonal_l1: box_kink_ref)
+    losses_ref, g_ref, _ = MT.loss_and_grads(Wt, x, y_box, y_cls, y_mask, C, torch.float64, relu_masks=engine_relu_masks(eng),
+                                             box_kink_ref=eng.export_outputs()[0].cpu().numpy())
     P = eng.params
     eng.opt.grad_norm(P.w_master, P.grad, P.scales, eng.gnorm_sq, eng.loss_sums[3:4])
     got = eng.losses()
@@ -413,7 +415,7 @@ def test_pyramid_variants_vs_oracle_f64(ctx, pyramid, anchors):
     eng.forward(torch.from_numpy(x).cuda())
     reg, cls, mask = [t.cpu().numpy() for t in eng.export_outputs()]
     losses_ref, g_ref, ref = MT.loss_and_grads(Wt, x, y_box, y_cls, y_mask, C, torch.float64, pyramid=pyramid,
-                                               relu_masks=engine_relu_masks(eng))
+                                               relu_masks=engine_relu_masks(eng), box_kink_ref=reg)
     assert_rows_within(reg, ref["3Dbox"].detach().numpy(), "3Dbox", TOL)
     assert_rows_within(cls, ref["cls"].detach().numpy(), "cls", TOL)
     assert_rows_within(mask, ref["mask"].detach().numpy(), "mask", TOL)
