@@ -168,6 +168,18 @@ int pp_ctx_set_row_block_out(pp_ctx* ctx, const unsigned char* flags, int* list)
 /* f32 tensor of n elements (n % 8 == 0) -> bf16 (hi, lo) planes with the same [rows][ld] geometry.  Convs that are
  * given planes for their gathered operand skip the conversion inside the kernel (the f32 pointer may then be NULL). */
 int pp_split_planes_bf16x3(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo);
+/* Format of every (hi, lo) plane pair the *_bf16x3 / *_v entry points of this context read and write -- and with it the arithmetic
+ * of the convolutions on them (csrc/planes_fmt.h).  0 (default): bf16 pairs, value = hi + lo, three bf16 MFMAs per product
+ * ("bf16x3", 4.5e-6 per launch against float64).  1: "P16" -- hi = IEEE half, lo = two e5m2 bytes per element (e5m2(x), e5m2((x - hi)
+ * * 2^12); swapped for weights), value = hi + lo8 * 2^-12; one f16 MFMA + half a block-scaled e5m2 MFMA per 16-deep step ("f16c8":
+ * 2 MFMA units per product instead of 3, 2.1e-5 per launch, |x| clamped to 28672).  Same packed geometry, same entry points; a
+ * tensor written under one format must be read under the same one.  pp_convert_planes re-encodes n elements (n % 8 == 0) from one
+ * format into the other, multiplied by scale2_dev[scale_index] when scale2_dev != NULL (pp_grad_scale_from_counts), and set to zero
+ * where the tensor whose hi plane is relu_src_hi (same geometry, either format; NULL: none) is not positive -- the ReLU a gradient
+ * passes when it crosses the boundary backwards. */
+int pp_ctx_set_planes_format(pp_ctx* ctx, int fmt);
+int pp_convert_planes(pp_ctx* ctx, size_t n, const void* src_hi, const void* src_lo, int src_fmt, void* dst_hi, void* dst_lo, int dst_fmt,
+                      const float* scale2_dev, int scale_index, const void* relu_src_hi);
 /* The gradient chain travels multiplied by a power of two (the hi plane holds IEEE halves, which stop at 6e-8; loss gradients are
  * ~1e-7): pp_grad_scale_from_counts writes scale2 = {2^G, 2^-G} with 2^G = 2^8 * 2^floor(log2(max(1, min_i counts[i]))) -- every loss
  * gradient of losses.py:22-68 / :321-408 is bounded by ~1 / max(1, positives of its head); pp_split_planes_scaled_bf16x3 is

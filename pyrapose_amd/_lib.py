@@ -90,6 +90,8 @@ _SIGS = {
     "pp_conv2d_nhwc_bwd_weight": (_i, [_p, C.POINTER(ConvDesc), _p, _p, _p, _p]),
     "pp_conv_split_weights_bf16x3": (_i, [_p, C.POINTER(ConvDesc), _p, _p, _p, _p, _p]),
     "pp_split_planes_bf16x3": (_i, [_p, _sz, _p, _p, _p]),
+    "pp_ctx_set_planes_format": (_i, [_p, _i]),
+    "pp_convert_planes": (_i, [_p, _sz, _p, _p, _i, _p, _p, _i, _p, _i, _p]),
     "pp_split_planes_scaled_bf16x3": (_i, [_p, _sz, _p, _p, _p, _p]),
     "pp_grad_scale_from_counts": (_i, [_p, _p, _i, _p]),
     "pp_ctx_set_grad_scale": (_i, [_p, _p]),

@@ -21,76 +21,32 @@
 // [4 k-octets][rows][8 x 16 bit], rows of octet o rotated by 2*o so that both the 16-byte stores of the staging
 // threads (4 threads per row) and the 512-byte fragment reads are bank-conflict free.
 #include "conv_common.h"
-#include "p16.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));  // (16-byte fragment container of the transposing LDS reads)
-typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
-typedef int intx8 __attribute__((ext_vector_type(8)));
-// E8M0 scales of the scaled MFMA in ONE register: byte 0 (opsel 0) = 115 = 2^-12 for the gathered operand, byte 1 (opsel 1) = 127 = 1
-#define P16_SCALES 0x7f73
+// Everything below is compiled once per plane format (PP_FMT = 0: bf16 pairs / bf16x3, PP_FMT = 1: P16 / f16c8; planes_fmt.h) with
+// internal linkage; the entry points carry the format in their name and conv3_dispatch.hip forwards pp_* to the build the
+// context asks for (pp_ctx_set_planes_format).
+#define PP_CAT_(a, b) a##b
+#define PP_CAT(a, b) PP_CAT_(a, b)
+#if PP_FMT == 1
+#define PP_API(name) PP_CAT(name, _fmt1)
+#else
+#define PP_API(name) PP_CAT(name, _fmt0)
+#endif
+namespace {
+#include "planes_fmt.h"
 
 __device__ __forceinline__ void split8(const float4& lo4, const float4& hi4, uint4* out_hi, uint4* out_lo) {
-  p16_encode2<false>(lo4.x, lo4.y, &out_hi->x, &out_lo->x);
-  p16_encode2<false>(lo4.z, lo4.w, &out_hi->y, &out_lo->y);
-  p16_encode2<false>(hi4.x, hi4.y, &out_hi->z, &out_lo->z);
-  p16_encode2<false>(hi4.z, hi4.w, &out_hi->w, &out_lo->w);
+  fmt_encode2(lo4.x, lo4.y, &out_hi->x, &out_lo->x);
+  fmt_encode2(lo4.z, lo4.w, &out_hi->y, &out_lo->y);
+  fmt_encode2(hi4.x, hi4.y, &out_hi->z, &out_lo->z);
+  fmt_encode2(hi4.z, hi4.w, &out_hi->w, &out_lo->w);
 }
 
 // AP: the gathered operand comes from pre-split (hi, lo) planes (pp_split_planes_bf16x3, same [rows][ld]
 // geometry as the f32 tensor) instead of being split from f32 while staging: no conversion VALU in the loop.
 __device__ __forceinline__ void split4(const float4& v4, uint2* out_hi, uint2* out_lo) {
-  p16_encode2<false>(v4.x, v4.y, &out_hi->x, &out_lo->x);
-  p16_encode2<false>(v4.z, v4.w, &out_hi->y, &out_lo->y);
-}
-
-// One 32-deep k-step of a (32 TM) x (32 TN) block set from the rotated LDS images (row_a / row_b: this lane's first tile row of
-// each operand; a_ok: bit a set = row block a is live, else it reads the all-zero slot `a_zero`): cross terms first (their
-// fragments die with them), one row block at a time, then the two f16 half-steps.
-template <int TM, int TN, int BM, int BN>
-__device__ __forceinline__ void mma_step_p16(floatx16 (&acc)[TM][TN], const uint4* Ahi, const uint4* Alo, const uint4* Bhi, const uint4* Blo,
-                                             int row_a, int row_b, int h, unsigned a_ok = ~0u, int a_zero = 0) {
-  {
-    intx8 bq[TN];
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int o = 2 * s + h;
-        const uint4 t = Blo[o * BN + ((row_b + b * 32 + 2 * o) & (BN - 1))];
-        bq[b][4 * s] = (int)t.x; bq[b][4 * s + 1] = (int)t.y; bq[b][4 * s + 2] = (int)t.z; bq[b][4 * s + 3] = (int)t.w;
-      }
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-      intx8 aq;
-      const bool ok = (a_ok >> a) & 1u;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int o = 2 * s + h;
-        const uint4 t = Alo[ok ? o * BM + ((row_a + a * 32 + 2 * o) & (BM - 1)) : a_zero];
-        aq[4 * s] = (int)t.x; aq[4 * s + 1] = (int)t.y; aq[4 * s + 2] = (int)t.z; aq[4 * s + 3] = (int)t.w;
-      }
-#pragma unroll
-      for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq, bq[b], acc[a][b], 1, 1, 0, P16_SCALES, 1, P16_SCALES);
-    }
-  }
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int o = 2 * s + h;
-    halfx8 bh[TN];
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      uint4 t = Bhi[o * BN + ((row_b + b * 32 + 2 * o) & (BN - 1))];
-      bh[b] = *reinterpret_cast<halfx8*>(&t);
-    }
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-      const bool ok = (a_ok >> a) & 1u;
-      uint4 t = Ahi[ok ? o * BM + ((row_a + a * 32 + 2 * o) & (BM - 1)) : a_zero];
-      const halfx8 ah = *reinterpret_cast<halfx8*>(&t);
-#pragma unroll
-      for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[b], acc[a][b], 0, 0, 0);
-    }
-  }
+  fmt_encode2(v4.x, v4.y, &out_hi->x, &out_lo->x);
+  fmt_encode2(v4.z, v4.w, &out_hi->y, &out_lo->y);
 }
 
 // ---- the PACKED plane layout ----
@@ -108,15 +64,15 @@ __device__ __forceinline__ float4 planes_ld4(const void* hi, const void* lo, lon
   const long long q = pk4(i4);
   const uint2 h = reinterpret_cast<const uint2*>(hi)[q], l = reinterpret_cast<const uint2*>(lo)[q];
   float4 v;
-  p16_value2(h.x, l.x, &v.x, &v.y);
-  p16_value2(h.y, l.y, &v.z, &v.w);
+  fmt_value2(h.x, l.x, &v.x, &v.y);
+  fmt_value2(h.y, l.y, &v.z, &v.w);
   return v;
 }
 // the hi plane alone: enough for the sign / zero test of a ReLU source (+1 / 0 per element)
 __device__ __forceinline__ float4 hi_ld4(const void* hi, long long i4) {
   const uint2 h = reinterpret_cast<const uint2*>(hi)[pk4(i4)];
-  return make_float4(p16_pos(h.x & 0xffffu) ? 1.f : 0.f, p16_pos(h.x >> 16) ? 1.f : 0.f, p16_pos(h.y & 0xffffu) ? 1.f : 0.f,
-                     p16_pos(h.y >> 16) ? 1.f : 0.f);
+  return make_float4(fmt_pos(h.x & 0xffffu) ? 1.f : 0.f, fmt_pos(h.x >> 16) ? 1.f : 0.f, fmt_pos(h.y & 0xffffu) ? 1.f : 0.f,
+                     fmt_pos(h.y >> 16) ? 1.f : 0.f);
 }
 __device__ __forceinline__ void planes_st4(void* hi, void* lo, long long i4, const float4& v) {
   uint2 oh, ol;
@@ -250,15 +206,15 @@ __device__ __forceinline__ void epilogue3(const IgemmParams& p, floatx16 (&acc)[
                 const unsigned sx = odd ? q.x : q.z, sy = odd ? q.y : q.w;
                 const unsigned rx = lane_xor1(sx), ry = lane_xor1(sy);
                 const unsigned hx = odd ? rx : q.x, hy = odd ? ry : q.y, lx = odd ? q.z : rx, ly = odd ? q.w : ry;
-                p16_value2(hx, lx, &ad[g].x, &ad[g].y);
-                p16_value2(hy, ly, &ad[g].z, &ad[g].w);
+                fmt_value2(hx, lx, &ad[g].x, &ad[g].y);
+                fmt_value2(hy, ly, &ad[g].z, &ad[g].w);
               }
               if (has_mask && mask_pl) {
                 const uint4 q = *reinterpret_cast<const uint4*>(&mk[g]);
                 const unsigned rx = lane_xor1(q.z), ry = lane_xor1(q.w);  // the even lane's second half
                 const unsigned hx = odd ? rx : q.x, hy = odd ? ry : q.y;
-                mk[g] = make_float4(p16_pos(hx & 0xffffu) ? 1.f : 0.f, p16_pos(hx >> 16) ? 1.f : 0.f, p16_pos(hy & 0xffffu) ? 1.f : 0.f,
-                                    p16_pos(hy >> 16) ? 1.f : 0.f);
+                mk[g] = make_float4(fmt_pos(hx & 0xffffu) ? 1.f : 0.f, fmt_pos(hx >> 16) ? 1.f : 0.f, fmt_pos(hy & 0xffffu) ? 1.f : 0.f,
+                                    fmt_pos(hy >> 16) ? 1.f : 0.f);
               }
               if (has_add) { v.x += ad[g].x; v.y += ad[g].y; v.z += ad[g].z; v.w += ad[g].w; }
               if (has_mask) {
@@ -428,7 +384,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
       advance();
       load_step();  // in flight under the MFMAs below
     }
-    mma_step_p16<TM, TN, BM, BN>(acc, Ahi, Alo, Bhi, Blo, wm * 32 * TM + il, wn * 32 * TN + il, h);
+    mma_step<TM, TN, BM, BN, 0>(acc, Ahi, Alo, Bhi, Blo, wm * 32 * TM + il, wn * 32 * TN + il, h);
     __syncthreads();  // every wave has read this step's tiles
     if (more) {
       store_step();
@@ -634,7 +590,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
     // (left alone the scheduler sinks the loads below the MFMAs, or pulls the conversion of the loaded tile -- and
     // with it the wait for the loads -- up to the first MFMA: pin loads | first half of the MFMAs | rest + conversion)
     __builtin_amdgcn_sched_barrier(0);
-    mma_step_p16<TM, TN, BM, BN>(acc, Ahi, Alo, Bhi, Blo, wm * 32 * TM + il, wn * 32 * TN + il, h);
+    mma_step<TM, TN, BM, BN, 2>(acc, Ahi, Alo, Bhi, Blo, wm * 32 * TM + il, wn * 32 * TN + il, h);
     split_step();     // conversion VALU issues while this wave's MFMAs drain
     __syncthreads();  // every wave has read this step's tiles
     store_step();
@@ -864,15 +820,11 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
     unsigned okm[(TM + 1) / 2];
 #pragma unroll
     for (int a = 0; a < (TM + 1) / 2; ++a) okm[a] = f_valid[a] & tap_bits;
-    // (cross terms first, one row block at a time, then the two f16 half-steps: mma_step_p16)
     unsigned a_ok = 0;
 #pragma unroll
     for (int a = 0; a < TM; ++a) a_ok |= (((okm[a >> 1] >> (16 * (a & 1))) & 0xffffu) != 0 ? 1u : 0u) << a;
     // padded taps read the all-zero slot: one address select per fragment
-    mma_step_p16<TM, TN, BM, BN>(acc, Ahi, Alo, Bhi, Blo, wm * 32 * TM + il + dx, wn * 32 * TN + il, h, a_ok, NO * BM);
-    // scheduling hint: interleave the LDS fragment reads of this step with its MFMAs (measured on the head shapes with the
-    // bf16x3 body: +3 % over a plain order, +1.7 % in the training step)
-    __builtin_amdgcn_iglp_opt(1);
+    mma_step<TM, TN, BM, BN, 1>(acc, Ahi, Alo, Bhi, Blo, wm * 32 * TM + il + dx, wn * 32 * TN + il, h, a_ok, NO * BM);
   };
 
   std::integral_constant<int, 0> t0;
@@ -1093,7 +1045,7 @@ __global__ void row_block_flags_planes_kernel(const uint2* __restrict__ hi, cons
     const int r = i / cols4, c = i - r * cols4;
     const long long o = pk4((long long)(r0 + r) * ld4 + c);
     const uint2 h = hi[o], l = lo[o];
-    any |= (((h.x | h.y) & 0x7fff7fffu) | ((l.x | l.y) & 0x7f7f7f7fu)) != 0u;  // sign bits of the halves / of the e5m2 bytes aside
+    any |= fmt_any_nonzero(h.x | h.y, l.x | l.y) ? 1 : 0;
   }
   any = __syncthreads_or(any);
   if (threadIdx.x == 0) flags[blk] = any ? 1 : 0;
@@ -1123,7 +1075,8 @@ __global__ void row_block_compact_kernel(const unsigned char* __restrict__ flags
   if (tid == 0) list[0] = base;
 }
 
-extern "C" int pp_row_block_list(pp_ctx* ctx, const float* x, int rows, int ld, int cols, unsigned char* flags, int* list) {
+}  // namespace
+extern "C" int PP_API(pp_row_block_list)(pp_ctx* ctx, const float* x, int rows, int ld, int cols, unsigned char* flags, int* list) {
   PP_REQUIRE_CTX(ctx);
   PP_CHECK_ARG(ctx, x && flags && list && rows > 0 && cols > 0 && cols <= ld && ld % 4 == 0 && pp_is_aligned16(x), PP_ERR_ARG,
                "pp_row_block_list: bad tensor (ld %% 4 == 0, 16-byte aligned)");
@@ -1134,15 +1087,21 @@ extern "C" int pp_row_block_list(pp_ctx* ctx, const float* x, int rows, int ld, 
   PP_CHECK_LAUNCH(ctx, "pp_row_block_list");
   return PP_OK;
 }
+namespace {
 
-extern "C" int pp_row_block_list_planes_within(pp_ctx* ctx, const void* x_hi, const void* x_lo, int rows, int ld, int cols,
+}  // namespace
+extern "C" int PP_API(pp_row_block_list_planes_within)(pp_ctx* ctx, const void* x_hi, const void* x_lo, int rows, int ld, int cols,
                                                const unsigned char* within, unsigned char* flags, int* list);
-extern "C" int pp_row_block_list_planes(pp_ctx* ctx, const void* x_hi, const void* x_lo, int rows, int ld, int cols, unsigned char* flags,
+namespace {
+}  // namespace
+extern "C" int PP_API(pp_row_block_list_planes)(pp_ctx* ctx, const void* x_hi, const void* x_lo, int rows, int ld, int cols, unsigned char* flags,
                                         int* list) {
-  return pp_row_block_list_planes_within(ctx, x_hi, x_lo, rows, ld, cols, nullptr, flags, list);
+  return PP_API(pp_row_block_list_planes_within)(ctx, x_hi, x_lo, rows, ld, cols, nullptr, flags, list);
 }
+namespace {
 
-extern "C" int pp_row_block_list_planes_within(pp_ctx* ctx, const void* x_hi, const void* x_lo, int rows, int ld, int cols,
+}  // namespace
+extern "C" int PP_API(pp_row_block_list_planes_within)(pp_ctx* ctx, const void* x_hi, const void* x_lo, int rows, int ld, int cols,
                                                const unsigned char* within, unsigned char* flags, int* list) {
   PP_REQUIRE_CTX(ctx);
   PP_CHECK_ARG(ctx, x_hi && x_lo && flags && list && rows > 0 && cols > 0 && cols <= ld && ld % 8 == 0 && pp_is_packed(x_hi, x_lo), PP_ERR_ARG,
@@ -1155,15 +1114,21 @@ extern "C" int pp_row_block_list_planes_within(pp_ctx* ctx, const void* x_hi, co
   PP_CHECK_LAUNCH(ctx, "pp_row_block_list_planes");
   return PP_OK;
 }
+namespace {
 
 static int split_planes_impl(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo, const float* scale);
-extern "C" int pp_split_planes_bf16x3(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo) {
+}  // namespace
+extern "C" int PP_API(pp_split_planes_bf16x3)(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo) {
   return split_planes_impl(ctx, n, src, hi, lo, nullptr);
 }
-extern "C" int pp_split_planes_scaled_bf16x3(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo, const float* scale_dev) {
+namespace {
+}  // namespace
+extern "C" int PP_API(pp_split_planes_scaled_bf16x3)(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo, const float* scale_dev) {
   return split_planes_impl(ctx, n, src, hi, lo, scale_dev);
 }
-extern "C" int pp_grad_scale_from_counts(pp_ctx* ctx, const int* counts_dev, int n_counts, float* scale2_dev) {
+namespace {
+}  // namespace
+extern "C" int PP_API(pp_grad_scale_from_counts)(pp_ctx* ctx, const int* counts_dev, int n_counts, float* scale2_dev) {
   PP_REQUIRE_CTX(ctx);
   PP_CHECK_ARG(ctx, counts_dev && scale2_dev && n_counts >= 1 && n_counts <= 16, PP_ERR_ARG, "pp_grad_scale_from_counts: bad arguments");
   static const int base_log2 = []() { const char* e = getenv("PP_GSCALE_LOG2"); const int v = e ? atoi(e) : 8; return v < -20 ? -20 : (v > 30 ? 30 : v); }();
@@ -1171,6 +1136,7 @@ extern "C" int pp_grad_scale_from_counts(pp_ctx* ctx, const int* counts_dev, int
   PP_CHECK_LAUNCH(ctx, "pp_grad_scale_from_counts");
   return PP_OK;
 }
+namespace {
 static int split_planes_impl(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo, const float* scale) {
   PP_REQUIRE_CTX(ctx);
   PP_CHECK_ARG(ctx, src && hi && lo && n % 8 == 0, PP_ERR_ARG, "pp_split_planes_bf16x3: n must be a multiple of 8");
@@ -1195,9 +1161,8 @@ __device__ __forceinline__ void split_weights_tile(int tap, int ci0, int co0, in
     const int ci = ci0 + j, co = co0 + tx;
     float v = 0.f;
     if (ci < cin && co < cout) v = w[((long long)tap * cin + ci) * ld_w + co];
-    unsigned h2, l2;
-    p16_encode2<true>(v, 0.f, &h2, &l2);  // the weights' byte order: [rem | e5m2(w) << 8]
-    const unsigned short uh = (unsigned short)h2, ul = (unsigned short)l2;
+    unsigned short uh, ul;
+    fmt_encode_weight(v, &uh, &ul);
     t_hi[j][tx] = uh;
     t_lo[j][tx] = ul;
     if (dg_hi && ci < cin && co < dg_ld) {  // bwd-data layout: [tap][ci][co], co contiguous
@@ -1243,7 +1208,8 @@ __global__ void split_weights_batch_kernel(int n_jobs, const pp_split_job* __res
                      (unsigned short*)j.dg_hi, (unsigned short*)j.dg_lo, dg_ld);
 }
 
-extern "C" int pp_conv_split_weights_bf16x3_batch(pp_ctx* ctx, int n_jobs, const pp_split_job* jobs_dev, int total_tiles) {
+}  // namespace
+extern "C" int PP_API(pp_conv_split_weights_bf16x3_batch)(pp_ctx* ctx, int n_jobs, const pp_split_job* jobs_dev, int total_tiles) {
   PP_REQUIRE_CTX(ctx);
   PP_CHECK_ARG(ctx, n_jobs >= 0 && total_tiles >= 0 && (n_jobs == 0 || jobs_dev), PP_ERR_ARG, "pp_conv_split_weights_bf16x3_batch: bad arguments");
   if (n_jobs == 0 || total_tiles == 0) return PP_OK;
@@ -1251,8 +1217,10 @@ extern "C" int pp_conv_split_weights_bf16x3_batch(pp_ctx* ctx, int n_jobs, const
   PP_CHECK_LAUNCH(ctx, "pp_conv_split_weights_bf16x3_batch");
   return PP_OK;
 }
+namespace {
 
-extern "C" int pp_conv_split_weights_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* w, void* fwd_hi, void* fwd_lo,
+}  // namespace
+extern "C" int PP_API(pp_conv_split_weights_bf16x3)(pp_ctx* ctx, const pp_conv_desc* d, const float* w, void* fwd_hi, void* fwd_lo,
                                             void* dg_hi, void* dg_lo) {
   PP_REQUIRE_CTX(ctx);
   int rc = check_desc(ctx, d, "pp_conv_split_weights_bf16x3");
@@ -1267,6 +1235,7 @@ extern "C" int pp_conv_split_weights_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, 
   PP_CHECK_LAUNCH(ctx, "pp_conv_split_weights_bf16x3");
   return PP_OK;
 }
+namespace {
 
 static bool igemm3_fast_ok(const IgemmParams& p, bool planes, int w_rows, int w_ld8) {
   // the branch-free loop needs a tap-linear gather and 31-bit byte offsets (see igemm3f_kernel)
@@ -1594,7 +1563,8 @@ static void dispatch3(pp_ctx* ctx, IgemmParams& p, const void* ahi, const void* 
   }
 }
 
-extern "C" int pp_conv2d_nhwc_fwd_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const void* x_hi, const void* x_lo,
+}  // namespace
+extern "C" int PP_API(pp_conv2d_nhwc_fwd_bf16x3)(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const void* x_hi, const void* x_lo,
                                          const void* w_hi, const void* w_lo, const float* bias, const float* residual, int ld_res,
                                          int relu, float* y, void* y_hi, void* y_lo) {
   PP_REQUIRE_CTX(ctx);
@@ -1654,10 +1624,12 @@ extern "C" int pp_conv2d_nhwc_fwd_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, con
   PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_fwd_bf16x3");
   return PP_OK;
 }
+namespace {
 
 // out_flags[b] = 1 when a flagged block of in_flags lies within one pixel (2-D, 32-row granularity) of block b of the row
 // space of a 3x3 stride-1 'same' conv d (the blocks of its input that the flagged blocks of its output read, and vice versa)
-extern "C" int pp_row_block_dilate(pp_ctx* ctx, const pp_conv_desc* d, const unsigned char* in_flags, unsigned char* out_flags) {
+}  // namespace
+extern "C" int PP_API(pp_row_block_dilate)(pp_ctx* ctx, const pp_conv_desc* d, const unsigned char* in_flags, unsigned char* out_flags) {
   PP_REQUIRE_CTX(ctx);
   int rc = check_desc(ctx, d, "pp_row_block_dilate");
   if (rc) return rc;
@@ -1674,6 +1646,7 @@ extern "C" int pp_row_block_dilate(pp_ctx* ctx, const pp_conv_desc* d, const uns
   PP_CHECK_LAUNCH(ctx, "pp_row_block_dilate");
   return PP_OK;
 }
+namespace {
 
 // The 7x7 stride-2 RGB stem on the bf16 path.  Input: the packed 4-channel image inside a zero frame [n_img][Hp][Wp][4] with
 // the image at (3, 3) (pp_pack_rgb_to_4_padded / pp_preprocess_caffe_u8_padded), Hp >= H + 6, Wp >= W + 8, Wp even.  Each
@@ -1681,7 +1654,8 @@ extern "C" int pp_row_block_dilate(pp_ctx* ctx, const pp_conv_desc* d, const uns
 // 32 "channels" that overlap between neighbouring pixels -- the gather of igemm3f needs nothing else: base offset of pixel
 // (2 oy + ty, 2 ox), 32 consecutive floats.  Weights: planes [7][cout][32] with plane row ty, column tx * 4 + c (zeros for
 // c == 3 and tx == 7), see Engine._build_stem.  224 of the executed 7 x 32 reduction steps are 147 algorithmic.
-extern "C" int pp_stem7x7s2_fwd_bf16x3(pp_ctx* ctx, int n_img, int H, int W, int Hp, int Wp, const float* x4p, const void* w_hi,
+}  // namespace
+extern "C" int PP_API(pp_stem7x7s2_fwd_bf16x3)(pp_ctx* ctx, int n_img, int H, int W, int Hp, int Wp, const float* x4p, const void* w_hi,
                                        const void* w_lo, int cout, const float* bias, int relu, float* y, int ld_y) {
   PP_REQUIRE_CTX(ctx);
   PP_CHECK_ARG(ctx, x4p && w_hi && w_lo && y && pp_is_aligned16(x4p) && pp_is_aligned16(y) && pp_is_aligned16(w_hi) && pp_is_aligned16(w_lo),
@@ -1708,8 +1682,10 @@ extern "C" int pp_stem7x7s2_fwd_bf16x3(pp_ctx* ctx, int n_img, int H, int W, int
   PP_CHECK_LAUNCH(ctx, "pp_stem7x7s2_fwd_bf16x3");
   return PP_OK;
 }
+namespace {
 
-extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* dy, const void* dy_hi, const void* dy_lo,
+}  // namespace
+extern "C" int PP_API(pp_conv2d_nhwc_bwd_data_bf16x3)(pp_ctx* ctx, const pp_conv_desc* d, const float* dy, const void* dy_hi, const void* dy_lo,
                                               const void* w_hi, const void* w_lo, const float* addend, int ld_add,
                                               const float* relu_src, int ld_rs, float* dx, void* dx_hi, void* dx_lo) {
   PP_REQUIRE_CTX(ctx);
@@ -1834,6 +1810,7 @@ extern "C" int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d
   PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_data_bf16x3");
   return PP_OK;
 }
+namespace {
 
 // ------------------------------------------------------------------------------------------------------------
 // weight gradient on the bf16 matrix cores:  dw[tap][ci][co] += sum_m x[gather(m,tap)][ci] * dy[m][co]
@@ -1858,74 +1835,6 @@ struct Wgrad3Params {
   const float* inv_scale;  // device scalar 2^-G (NULL: 1): dy travels multiplied by 2^G (pp_ctx_set_grad_scale), dW / dbias leave unscaled
 };
 
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned short* lds, int elem_off0, int elem_off1) {
-  typedef __attribute__((address_space(3))) shortx4 lds_s4;
-  shortx4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(lds + elem_off0));
-  shortx4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(lds + elem_off1));
-  typedef short shortx8 __attribute__((ext_vector_type(8)));
-  shortx8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return *reinterpret_cast<bf16x8*>(&v);
-}
-
-// One 32-pixel step of the weight gradient's (32 TM) x (32 TN) blocks from the pixel-major LDS images through the transposing
-// reads: the lo fragments of the two 16-pixel halves are the e5m2 operands of ONE scaled MFMA (a (hi8, lo8) pair travels
-// through ds_read_b64_tr_b16 as one 16-bit unit); both operands are gathered-type tensors, so the units of dy swap their bytes
-// (8 v_perm per column block), then the two f16 half-steps.
-template <int TM, int TN>
-__device__ __forceinline__ void wgrad_step_p16(floatx16 (&acc)[TM][TN], const unsigned short* Xhi, const unsigned short* Xlo,
-                                               const unsigned short* Ghi, const unsigned short* Glo, int PA, int PB, int xcol0, int gcol0,
-                                               int hh, int gq) {
-  {
-    intx8 gq8[TN];
-#pragma unroll
-    for (int c = 0; c < TN; ++c)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int row0 = 16 * s + 8 * hh + gq, col = gcol0 + c * 32;
-        const bf16x8 t = tr_frag(Glo, row0 * PB + col, (row0 + 4) * PB + col);
-        const uint4 u = *reinterpret_cast<const uint4*>(&t);
-        gq8[c][4 * s] = (int)__builtin_amdgcn_perm(u.x, u.x, 0x02030001u);
-        gq8[c][4 * s + 1] = (int)__builtin_amdgcn_perm(u.y, u.y, 0x02030001u);
-        gq8[c][4 * s + 2] = (int)__builtin_amdgcn_perm(u.z, u.z, 0x02030001u);
-        gq8[c][4 * s + 3] = (int)__builtin_amdgcn_perm(u.w, u.w, 0x02030001u);
-      }
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-      intx8 xq8;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int row0 = 16 * s + 8 * hh + gq, col = xcol0 + a * 32;
-        const bf16x8 t = tr_frag(Xlo, row0 * PA + col, (row0 + 4) * PA + col);
-        const uint4 u = *reinterpret_cast<const uint4*>(&t);
-        xq8[4 * s] = (int)u.x; xq8[4 * s + 1] = (int)u.y; xq8[4 * s + 2] = (int)u.z; xq8[4 * s + 3] = (int)u.w;
-      }
-#pragma unroll
-      for (int c = 0; c < TN; ++c) acc[a][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xq8, gq8[c], acc[a][c], 1, 1, 0, P16_SCALES, 1, P16_SCALES);
-    }
-  }
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int row0 = 16 * s + 8 * hh + gq;
-    halfx8 gh[TN];
-#pragma unroll
-    for (int c = 0; c < TN; ++c) {
-      const int col = gcol0 + c * 32;
-      const bf16x8 t = tr_frag(Ghi, row0 * PB + col, (row0 + 4) * PB + col);
-      gh[c] = *reinterpret_cast<const halfx8*>(&t);
-    }
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-      const int col = xcol0 + a * 32;
-      const bf16x8 t = tr_frag(Xhi, row0 * PA + col, (row0 + 4) * PA + col);
-      const halfx8 xh = *reinterpret_cast<const halfx8*>(&t);
-#pragma unroll
-      for (int c = 0; c < TN; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, gh[c], acc[a][c], 0, 0, 0);
-    }
-    if (s == 0) __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// AP: x and dy come from pre-split bf16 planes (16-byte = 8-channel chunks, no conversion in the loop).
 template <int TM, int TN, bool AP>
 __global__ __launch_bounds__(256, (TM * TN == 4) ? 2 : 3) void wgrad3_kernel(const Wgrad3Params p, const float* __restrict__ g_src,
                                                                             const float* __restrict__ g_dy,
@@ -2053,7 +1962,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 2 : 3) void wgrad3_kernel(con
             const unsigned int hw[4] = {pbh[j].x, pbh[j].y, pbh[j].z, pbh[j].w}, lw[4] = {pbl[j].x, pbl[j].y, pbl[j].z, pbl[j].w};
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) p16_value2(hw[e], lw[e], &v[2 * e], &v[2 * e + 1]);
+            for (int e = 0; e < 4; ++e) fmt_value2(hw[e], lw[e], &v[2 * e], &v[2 * e + 1]);
             bsum[2 * j].x += v[0]; bsum[2 * j].y += v[1]; bsum[2 * j].z += v[2]; bsum[2 * j].w += v[3];
             bsum[2 * j + 1].x += v[4]; bsum[2 * j + 1].y += v[5]; bsum[2 * j + 1].z += v[6]; bsum[2 * j + 1].w += v[7];
           }
@@ -2101,7 +2010,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 2 : 3) void wgrad3_kernel(con
   for (int step = 0; step < n_steps; ++step) {
     const bool more = step + 1 < n_steps;
     if (more) load_step();
-    wgrad_step_p16<TM, TN>(acc, Xhi, Xlo, Ghi, Glo, PA, PB, wm * 32 * TM + cbase + 4 * gp, wn * 32 * TN + cbase + 4 * gp, hh, gq);
+    wgrad_step<TM, TN>(acc, Xhi, Xlo, Ghi, Glo, PA, PB, wm * 32 * TM + cbase + 4 * gp, wn * 32 * TN + cbase + 4 * gp, hh, gq);
     __syncthreads();
     if (more) {
       store_step();
@@ -2310,7 +2219,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
         const unsigned int hw4[4] = {rb[j].x, rb[j].y, rb[j].z, rb[j].w}, lw4[4] = {rbl[j].x, rbl[j].y, rbl[j].z, rbl[j].w};
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) p16_value2(hw4[e], lw4[e], &v[2 * e], &v[2 * e + 1]);
+        for (int e = 0; e < 4; ++e) fmt_value2(hw4[e], lw4[e], &v[2 * e], &v[2 * e + 1]);
         bsum[2 * j].x = fmaf(v[0], bmask, bsum[2 * j].x); bsum[2 * j].y = fmaf(v[1], bmask, bsum[2 * j].y);
         bsum[2 * j].z = fmaf(v[2], bmask, bsum[2 * j].z); bsum[2 * j].w = fmaf(v[3], bmask, bsum[2 * j].w);
         bsum[2 * j + 1].x = fmaf(v[4], bmask, bsum[2 * j + 1].x); bsum[2 * j + 1].y = fmaf(v[5], bmask, bsum[2 * j + 1].y);
@@ -2374,7 +2283,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4) ? 3 : 4) void wgrad3f_kernel(co
       next_row();
       load_step();  // past the last step m >= m_end: zeros, never stored
       __builtin_amdgcn_sched_barrier(0);
-      wgrad_step_p16<TM, TN>(acc, Xhi, Xlo, Ghi, Glo, PA, PB, wm * 32 * TM + cbase + 4 * gp, wn * 32 * TN + cbase + 4 * gp, hh, gq);
+      wgrad_step<TM, TN>(acc, Xhi, Xlo, Ghi, Glo, PA, PB, wm * 32 * TM + cbase + 4 * gp, wn * 32 * TN + cbase + 4 * gp, hh, gq);
       split_step(with_bias);
       __syncthreads();
       store_step();
@@ -2543,7 +2452,8 @@ static void launch_wgrad3(pp_ctx* ctx, Wgrad3Params& p, const float* x, const fl
                        (const uint4*)nullptr, (const uint4*)nullptr, (const uint4*)nullptr, (const uint4*)nullptr, dw, dbias);
 }
 
-extern "C" int pp_conv2d_nhwc_bwd_weight_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const float* dy, const void* x_hi,
+}  // namespace
+extern "C" int PP_API(pp_conv2d_nhwc_bwd_weight_bf16x3)(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const float* dy, const void* x_hi,
                                                 const void* x_lo, const void* dy_hi, const void* dy_lo, float* dw, float* dbias) {
   PP_REQUIRE_CTX(ctx);
   const int* skip_list = ctx->skip_list;  // one-shot (pp_ctx_set_row_block_skip)
@@ -2587,3 +2497,5 @@ extern "C" int pp_conv2d_nhwc_bwd_weight_bf16x3(pp_ctx* ctx, const pp_conv_desc*
   PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_weight_bf16x3");
   return PP_OK;
 }
+namespace {
+}  // namespace

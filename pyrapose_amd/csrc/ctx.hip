@@ -80,6 +80,13 @@ extern "C" int pp_ctx_set_row_block_out(pp_ctx* ctx, const unsigned char* flags,
   return PP_OK;
 }
 
+extern "C" int pp_ctx_set_planes_format(pp_ctx* ctx, int fmt) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, fmt == 0 || fmt == 1, PP_ERR_ARG, "pp_ctx_set_planes_format: 0 (bf16 pairs) or 1 (P16)");
+  ctx->planes_fmt = fmt;
+  return PP_OK;
+}
+
 extern "C" int pp_ctx_set_grad_scale(pp_ctx* ctx, const float* scale2_dev) {
   PP_REQUIRE_CTX(ctx);
   ctx->grad_scale = scale2_dev;  // persistent (NULL: gradients are unscaled)

@@ -177,11 +177,35 @@ struct TV {
   const float* f;
   const void* hi;
   const void* lo;
+  int fmt;  // plane format of hi / lo: 0 = bf16 pairs, 1 = P16 (csrc/planes_fmt.h); taken from the context
 };
-static inline TV tv_of(const pp_tview* v) {
-  TV t = {nullptr, nullptr, nullptr};
+static inline TV tv_of(const pp_tview* v, const pp_ctx* ctx = nullptr) {
+  TV t = {nullptr, nullptr, nullptr, ctx ? ctx->planes_fmt : 0};
   if (v) { t.f = v->f32; t.hi = v->hi; t.lo = v->lo; }
   return t;
+}
+// two elements <-> their dword in each plane, in either format
+__device__ __forceinline__ void tv_value2(int fmt, unsigned h2, unsigned l2, float* e0, float* e1) {
+  if (fmt == 1) {
+    p16_value2(h2, l2, e0, e1);
+  } else {
+    *e0 = __uint_as_float(h2 << 16) + __uint_as_float(l2 << 16);
+    *e1 = __uint_as_float(h2 & 0xffff0000u) + __uint_as_float(l2 & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void tv_encode2(int fmt, float v0, float v1, unsigned* h2, unsigned* l2) {
+  if (fmt == 1) {
+    p16_encode2<false>(v0, v1, h2, l2);
+  } else {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 h, l;
+    h[0] = (__bf16)v0;
+    h[1] = (__bf16)v1;
+    l[0] = (__bf16)(v0 - (float)h[0]);
+    l[1] = (__bf16)(v1 - (float)h[1]);
+    *h2 = __builtin_bit_cast(unsigned, h);
+    *l2 = __builtin_bit_cast(unsigned, l);
+  }
 }
 static inline bool tv_null(const TV& t) { return !t.f && !t.hi; }
 static inline bool tv_ok_in(const TV& t) { return (t.f != nullptr) != (t.hi != nullptr) && pp_is_packed(t.hi, t.lo) && pp_is_aligned16(t.f); }
@@ -193,10 +217,10 @@ __device__ __forceinline__ F8 tv_ld8(const TV& t, size_t i8) {
   F8 v;
   if (t.hi) {
     const uint4 h = reinterpret_cast<const uint4*>(t.hi)[2 * i8], l = reinterpret_cast<const uint4*>(t.hi)[2 * i8 + 1];
-    p16_value2(h.x, l.x, &v.a.x, &v.a.y);
-    p16_value2(h.y, l.y, &v.a.z, &v.a.w);
-    p16_value2(h.z, l.z, &v.b.x, &v.b.y);
-    p16_value2(h.w, l.w, &v.b.z, &v.b.w);
+    tv_value2(t.fmt, h.x, l.x, &v.a.x, &v.a.y);
+    tv_value2(t.fmt, h.y, l.y, &v.a.z, &v.a.w);
+    tv_value2(t.fmt, h.z, l.z, &v.b.x, &v.b.y);
+    tv_value2(t.fmt, h.w, l.w, &v.b.z, &v.b.w);
     return v;
   }
   v.a = reinterpret_cast<const float4*>(t.f)[2 * i8];
@@ -210,10 +234,10 @@ __device__ __forceinline__ void tv_st8(const TV& t, size_t i8, const F8& v) {
   }
   if (t.hi) {
     uint4 h, l;
-    p16_encode2<false>(v.a.x, v.a.y, &h.x, &l.x);
-    p16_encode2<false>(v.a.z, v.a.w, &h.y, &l.y);
-    p16_encode2<false>(v.b.x, v.b.y, &h.z, &l.z);
-    p16_encode2<false>(v.b.z, v.b.w, &h.w, &l.w);
+    tv_encode2(t.fmt, v.a.x, v.a.y, &h.x, &l.x);
+    tv_encode2(t.fmt, v.a.z, v.a.w, &h.y, &l.y);
+    tv_encode2(t.fmt, v.b.x, v.b.y, &h.z, &l.z);
+    tv_encode2(t.fmt, v.b.z, v.b.w, &h.w, &l.w);
     uint4* dst = reinterpret_cast<uint4*>(const_cast<void*>(t.hi));
     dst[2 * i8] = h;
     dst[2 * i8 + 1] = l;
@@ -297,7 +321,7 @@ __global__ void merge_planes_kernel(size_t n8, const TV src, float4* __restrict_
 
 extern "C" int pp_add_n_v(pp_ctx* ctx, size_t n, const pp_tview* a, const pp_tview* b, const pp_tview* c, const pp_tview* out) {
   PP_REQUIRE_CTX(ctx);
-  const TV ta = tv_of(a), tb = tv_of(b), tc = tv_of(c), to = tv_of(out);
+  const TV ta = tv_of(a, ctx), tb = tv_of(b, ctx), tc = tv_of(c, ctx), to = tv_of(out, ctx);
   PP_CHECK_ARG(ctx, n % 8 == 0 && tv_ok_in(ta) && (tv_null(tb) || tv_ok_in(tb)) && (tv_null(tc) || tv_ok_in(tc)) && tv_ok_out(to), PP_ERR_ARG,
                "pp_add_n_v: bad views (n %% 8 == 0; an input is f32 or packed planes, 16-byte aligned)");
   if (n == 0) return PP_OK;
@@ -308,7 +332,7 @@ extern "C" int pp_add_n_v(pp_ctx* ctx, size_t n, const pp_tview* a, const pp_tvi
 
 extern "C" int pp_relu_fwd_v(pp_ctx* ctx, size_t n, const pp_tview* x, const pp_tview* y) {
   PP_REQUIRE_CTX(ctx);
-  const TV tx = tv_of(x), ty = tv_of(y);
+  const TV tx = tv_of(x, ctx), ty = tv_of(y, ctx);
   PP_CHECK_ARG(ctx, n % 8 == 0 && tv_ok_in(tx) && tv_ok_out(ty), PP_ERR_ARG, "pp_relu_fwd_v: bad views");
   if (n == 0) return PP_OK;
   hipLaunchKernelGGL(relu_v_kernel, dim3(grid_for(n / 8, 256, ctx)), dim3(256), 0, ctx->stream, n / 8, tx, ty);
@@ -319,7 +343,7 @@ extern "C" int pp_relu_fwd_v(pp_ctx* ctx, size_t n, const pp_tview* x, const pp_
 extern "C" int pp_upsample_nearest_add_fwd_v(pp_ctx* ctx, int n_img, int sh, int sw, int th, int tw, int c, const pp_tview* src,
                                              const pp_tview* other, const pp_tview* out) {
   PP_REQUIRE_CTX(ctx);
-  const TV ts = tv_of(src), to = tv_of(other), tout = tv_of(out);
+  const TV ts = tv_of(src, ctx), to = tv_of(other, ctx), tout = tv_of(out, ctx);
   PP_CHECK_ARG(ctx, n_img > 0 && sh > 0 && sw > 0 && th > 0 && tw > 0 && c > 0 && c % 8 == 0, PP_ERR_SHAPE, "pp_upsample_nearest_add_fwd_v: bad shape (c %% 8 == 0)");
   PP_CHECK_ARG(ctx, tv_ok_in(ts) && (tv_null(to) || tv_ok_in(to)) && tv_ok_out(tout), PP_ERR_ARG, "pp_upsample_nearest_add_fwd_v: bad views");
   size_t total = (size_t)n_img * th * tw * (c / 8);
@@ -332,7 +356,7 @@ extern "C" int pp_upsample_nearest_add_fwd_v(pp_ctx* ctx, int n_img, int sh, int
 extern "C" int pp_upsample_nearest_add_bwd_v(pp_ctx* ctx, int n_img, int sh, int sw, int th, int tw, int c, const pp_tview* dtarget,
                                              const pp_tview* base, const pp_tview* dsrc) {
   PP_REQUIRE_CTX(ctx);
-  const TV td = tv_of(dtarget), tb = tv_of(base), ts = tv_of(dsrc);
+  const TV td = tv_of(dtarget, ctx), tb = tv_of(base, ctx), ts = tv_of(dsrc, ctx);
   PP_CHECK_ARG(ctx, n_img > 0 && sh > 0 && sw > 0 && th > 0 && tw > 0 && c > 0 && c % 8 == 0, PP_ERR_SHAPE, "pp_upsample_nearest_add_bwd_v: bad shape (c %% 8 == 0)");
   PP_CHECK_ARG(ctx, tv_ok_in(td) && (tv_null(tb) || tv_ok_in(tb)) && tv_ok_out(ts), PP_ERR_ARG, "pp_upsample_nearest_add_bwd_v: bad views");
   size_t total = (size_t)n_img * sh * sw * (c / 8);
@@ -342,12 +366,54 @@ extern "C" int pp_upsample_nearest_add_bwd_v(pp_ctx* ctx, int n_img, int sh, int
   return PP_OK;
 }
 
+// planes of one format -> planes of the other (the boundary between the backbone's bf16 pairs and the P16 tensors of FPN + heads):
+// dst = encode_dst(decode_src(src) * scale[scale_index]) (scale NULL: 1; the gradient chain of the P16 side travels scaled);
+// relu_hi: hi plane of the tensor whose ReLU this gradient passes on the way (zero where that tensor is not positive; the sign
+// test of a hi half is the same in both formats)
+__global__ void convert_planes_kernel(size_t n8, const TV src, const TV dst, const float* __restrict__ scale, int scale_index,
+                                      const uint4* __restrict__ relu_hi) {
+  const float sc = scale ? scale[scale_index] : 1.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    F8 v = tv_ld8(src, i);
+    v.a.x *= sc; v.a.y *= sc; v.a.z *= sc; v.a.w *= sc;
+    v.b.x *= sc; v.b.y *= sc; v.b.z *= sc; v.b.w *= sc;
+    if (relu_hi) {
+      const uint4 m = relu_hi[2 * i];
+      if ((short)(m.x & 0xffffu) <= 0) v.a.x = 0.f;
+      if ((short)(m.x >> 16) <= 0) v.a.y = 0.f;
+      if ((short)(m.y & 0xffffu) <= 0) v.a.z = 0.f;
+      if ((short)(m.y >> 16) <= 0) v.a.w = 0.f;
+      if ((short)(m.z & 0xffffu) <= 0) v.b.x = 0.f;
+      if ((short)(m.z >> 16) <= 0) v.b.y = 0.f;
+      if ((short)(m.w & 0xffffu) <= 0) v.b.z = 0.f;
+      if ((short)(m.w >> 16) <= 0) v.b.w = 0.f;
+    }
+    tv_st8(dst, i, v);
+  }
+}
+
+extern "C" int pp_convert_planes(pp_ctx* ctx, size_t n, const void* src_hi, const void* src_lo, int src_fmt, void* dst_hi, void* dst_lo,
+                                 int dst_fmt, const float* scale2_dev, int scale_index, const void* relu_src_hi) {
+  PP_REQUIRE_CTX(ctx);
+  PP_CHECK_ARG(ctx, src_hi && dst_hi && n % 8 == 0 && pp_is_packed(src_hi, src_lo) && pp_is_packed(dst_hi, dst_lo) &&
+                        pp_is_aligned16(relu_src_hi), PP_ERR_ARG,
+               "pp_convert_planes: null tensor, planes not packed, or n %% 8 != 0");
+  PP_CHECK_ARG(ctx, (src_fmt == 0 || src_fmt == 1) && (dst_fmt == 0 || dst_fmt == 1) && (scale_index == 0 || scale_index == 1), PP_ERR_ARG,
+               "pp_convert_planes: formats are 0 (bf16 pairs) or 1 (P16), scale_index 0 or 1");
+  if (n == 0) return PP_OK;
+  TV s = {nullptr, src_hi, src_lo, src_fmt}, d = {nullptr, dst_hi, dst_lo, dst_fmt};
+  hipLaunchKernelGGL(convert_planes_kernel, dim3(grid_for(n / 8, 256, ctx)), dim3(256), 0, ctx->stream, n / 8, s, d, scale2_dev, scale_index,
+                     (const uint4*)relu_src_hi);
+  PP_CHECK_LAUNCH(ctx, "pp_convert_planes");
+  return PP_OK;
+}
+
 extern "C" int pp_merge_planes_bf16x3(pp_ctx* ctx, size_t n, const void* hi, const void* lo, float* dst) {
   PP_REQUIRE_CTX(ctx);
   PP_CHECK_ARG(ctx, hi && lo && dst && n % 8 == 0 && pp_is_packed(hi, lo) && pp_is_aligned16(dst), PP_ERR_ARG,
                "pp_merge_planes_bf16x3: null / unaligned tensor, planes not packed, or n %% 8 != 0");
   if (n == 0) return PP_OK;
-  TV t = {nullptr, hi, lo};
+  TV t = {nullptr, hi, lo, ctx->planes_fmt};
   hipLaunchKernelGGL(merge_planes_kernel, dim3(grid_for(n / 8, 256, ctx)), dim3(256), 0, ctx->stream, n / 8, t, (float4*)dst);
   PP_CHECK_LAUNCH(ctx, "pp_merge_planes_bf16x3");
   return PP_OK;

@@ -24,6 +24,7 @@ struct pp_ctx {
   const unsigned char* skip_flags;
   const unsigned char* out_flags;    // one-shot: the next bf16x3 forward call computes the flagged 32-row output blocks only
   int* out_list;                     //           (pp_ctx_set_row_block_out; list = its scratch)
+  int planes_fmt;                    // format of every (hi, lo) plane pair this context sees: 0 = bf16 pairs (bf16x3), 1 = P16 (f16c8)
   const float* grad_scale;           // device {2^G, 2^-G}: the gradient planes this context's weight gradients read carry the factor 2^G
 };
 

@@ -45,8 +45,9 @@ class Act(object):
     """A level-major activation matrix [rows, ld] (see pp_rowspace), stored as float32 (`t`) or -- what the bf16x3 convs
     produce and consume in the default mode -- as a pair of bf16 planes (`pl` = (hi, lo) int16 [rows, ld], value = hi + lo)."""
 
-    def __init__(self, name, n_img, shapes, C, ld=None, t=None, needs_grad=False, relu=False, pl=None, planes=False):
+    def __init__(self, name, n_img, shapes, C, ld=None, t=None, needs_grad=False, relu=False, pl=None, planes=False, fmt=0):
         self.name, self.n_img, self.shapes, self.C = name, n_img, list(shapes), C
+        self.fmt = int(fmt)  # plane format of `pl`: 0 = bf16 pairs, 1 = P16 (csrc/planes_fmt.h)
         self.ld = ld if ld is not None else C
         self.rows = sum(n_img * h * w for h, w in self.shapes)
         if planes:
@@ -70,7 +71,7 @@ class Act(object):
         if self.t is not None:
             return self.t
         out = torch.empty((self.rows, self.ld), dtype=torch.float32, device="cuda")
-        ops.merge_planes3(ctx, self.pl, out)
+        ops.merge_planes3(ctx.twin(self.fmt), self.pl, out)
         return out
 
 
@@ -85,14 +86,14 @@ def _view(t, pl):
 
 class Grad(object):
     """A gradient matrix: float32 (`t`) and / or bf16 planes (`pl`); rows(a, b) = the same for a row range."""
-    __slots__ = ("t", "pl", "within")
+    __slots__ = ("t", "pl", "within", "fmt")
 
-    def __init__(self, t, pl=None):
-        self.t, self.pl = t, pl
+    def __init__(self, t, pl=None, fmt=0):
+        self.t, self.pl, self.fmt = t, pl, int(fmt)  # fmt: plane format of `pl` (a P16 gradient also carries the factor 2^G)
         self.within = None  # uint8 flags of the only 32-row blocks that can hold a non-zero (a sparse data gradient without addend)
 
     def rows(self, r0, r1):
-        return Grad(None if self.t is None else self.t[r0:r1], None if self.pl is None else (self.pl[0][r0:r1], self.pl[1][r0:r1]))
+        return Grad(None if self.t is None else self.t[r0:r1], None if self.pl is None else (self.pl[0][r0:r1], self.pl[1][r0:r1]), self.fmt)
 
     def view(self):
         return _view(self.t, self.pl)
@@ -247,8 +248,19 @@ class Engine(object):
         # conv arithmetic: "bf16x3" (default) = 3 x bf16 MFMA per product, f32 accumulation (conv3.hip; ~2^-16 per
         # product, whole-graph outputs within 2e-5 of the f32 path) for every conv except the 3-channel stem;
         # "f32" = exact f32 MFMA everywhere (conv.hip).  Both hold the 1e-3 head-output bar.
-        self.conv_mode = conv_mode or _os.environ.get("PP_CONV_MODE", "bf16x3")
-        assert self.conv_mode in ("f32", "bf16x3"), self.conv_mode
+        # conv_mode / PP_CONV_MODE: "f32" (exact f32 MFMA), or the plane-stored family with one of three arithmetics:
+        #   "bf16x3"  every layer on bf16 pairs, three bf16 MFMAs per product (4.5e-6 per launch against float64);
+        #   "f16c8"   every layer on P16 planes, one f16 MFMA + half a block-scaled e5m2 MFMA per 16-deep step (2 units per product
+        #             instead of 3, 2.1e-5 per launch, 1.15-1.19x faster on MFMA-bound launches);
+        #   "mixed"   (default) the backbone on bf16x3 -- its ~50 HBM- / latency-bound layers are where rounding accumulates and
+        #             where MFMA work is not what costs -- and the MFMA-bound FPN + heads on f16c8; C3 / C4 / C5 and the gradients
+        #             flowing back into them are re-encoded at the boundary (pp_convert_planes).
+        mode = conv_mode or _os.environ.get("PP_CONV_MODE", "mixed")
+        assert mode in ("f32", "bf16x3", "f16c8", "mixed"), mode
+        if mode in ("f16c8", "mixed") and _os.environ.get("PP_PLANES", "1") == "0":
+            mode = "bf16x3"  # float32 storage (PP_PLANES=0) exists for the bf16x3 arithmetic only
+        self.arith = mode
+        self.conv_mode = "f32" if mode == "f32" else "bf16x3"  # the kernel family (csrc/conv.hip or csrc/conv3.hip)
         # Storage format of activations and gradients in bf16x3 mode (PP_PLANES=0 turns it off): every tensor that a bf16x3 conv
         # produces is written as bf16 (hi, lo) planes ONLY -- 4 bytes per element like float32 -- and stays in that format
         # through the FPN's adds / resampling; convs read their gathered operand, the weight gradients both operands, and the
@@ -300,10 +312,10 @@ class Engine(object):
         # every bwd-data / pointwise launch, and is divided out by the weight-gradient launches (pp_ctx_set_grad_scale).
         self.gscale = None
         from ._lib import MISSING as _missing
-        if self.train and self.po and "pp_grad_scale_from_counts" not in _missing:
+        if self.train and self.po and self.arith in ("f16c8", "mixed") and "pp_grad_scale_from_counts" not in _missing:
             self.gscale = torch.ones((2,), dtype=torch.float32, device="cuda")
             for c in self.ctxs:
-                ops.set_grad_scale(c, self.gscale)
+                ops.set_grad_scale(c.twin(1), self.gscale)  # (bf16-pair gradients are unscaled: only the P16 contexts divide it out)
         self._lane = 0
         self.trunk_lanes = os.environ.get("PP_TRUNK_LANES", "1") != "0"  # backbone shortcut / FPN level 4-5 chains on lane 1
         # Prefix lane (training with conv1 + res2 frozen, the reference's setting): the frozen prefix is a pure function of
@@ -376,10 +388,33 @@ class Engine(object):
             cur.wait_stream(self.streams[0])
 
     # ------------------------------------------------------------------------------------ forward plan
-    def _new_act(self, name, shapes, C, ld=None, needs_grad=False, relu=False, t=None, pl=None, planes=False):
-        a = Act(name, self.B, shapes, C, ld, t, needs_grad, relu, pl, planes)
+    def _new_act(self, name, shapes, C, ld=None, needs_grad=False, relu=False, t=None, pl=None, planes=False, fmt=0):
+        a = Act(name, self.B, shapes, C, ld, t, needs_grad, relu, pl, planes, fmt)
         self.acts[name] = a
         return a
+
+    def _fmt(self, spec_name):
+        """plane format / arithmetic of a layer: 0 = bf16 pairs (bf16x3), 1 = P16 (f16c8)"""
+        if self.arith == "f16c8":
+            return 1
+        if self.arith == "mixed":
+            return 0 if spec_name.startswith(("conv1", "res")) else 1
+        return 0
+
+    def _convert(self, x, fmt):
+        """`x` re-encoded into plane format `fmt` (one pointwise pass; cached per tensor): the boundary between the two arithmetics"""
+        if x.pl is None or x.fmt == fmt:
+            return x
+        cache = x.__dict__.setdefault("_converted", {})
+        if fmt in cache:
+            return cache[fmt]
+        out = self._new_act(x.name + ":fmt%d" % fmt, x.shapes, x.C, x.ld, x.needs_grad, False, planes=True, fmt=fmt)
+        lane = self._lane
+        ctx = self.ctxs[lane]
+        self._push(Op(lambda: ops.convert_planes(ctx, x.pl, x.fmt, out.pl, fmt), "pointwise", "convert:" + x.name, lane=lane), (x,), out)
+        self.graph_ops.append(dict(kind="convert", y=out, x=x))
+        cache[fmt] = out
+        return out
 
     def _on(self, lane):
         """`with self._on(1): ...` builds the enclosed launches on side lane 1 (lane 0 when PP_LANES=1)"""
@@ -437,16 +472,20 @@ class Engine(object):
             out_shapes.append((oh, ow))
         # head outputs are padded to 32 channels in bf16x3 mode (the bf16 data-gradient kernel reduces 32 channels per step)
         ld_y = out_ld if out_ld is not None else _ru(s.cout, 32 if self.conv_mode == "bf16x3" else 16)
+        fmt = self._fmt(spec_name)
+        x = self._convert(x, fmt)
+        if residual is not None:
+            residual = self._convert(residual, fmt)
         needs_grad = self.train and (s.trainable or x.needs_grad or (residual is not None and residual.needs_grad))
         bf3 = self.conv_mode == "bf16x3" and s.cin % 32 == 0
         y_planes = bf3 and self.po and not f32_out and ld_y % 8 == 0
-        y = self._new_act(out_name or spec_name, out_shapes, s.cout, ld_y, needs_grad, relu, out_t, out_pl, y_planes)
+        y = self._new_act(out_name or spec_name, out_shapes, s.cout, ld_y, needs_grad, relu, out_t, out_pl, y_planes, fmt)
         ek = self.params.entries[spec_name + "/kernel"]
         desc = ops.make_conv_desc(self.B, x.shapes, out_shapes, cin_eff, s.cout, k, st, pt, pl, x.ld, ld_y, ek["ld"])
         w = self.params.view(self.params.w_eff, spec_name + "/kernel")
         b = self.params.view(self.params.w_eff, spec_name + "/bias")
         lane = self._lane
-        ctx = self.ctxs[lane]
+        ctx = self.ctxs[lane].twin(fmt)
         flops = 2.0 * y.rows * k * k * s.cin * s.cout
         pl = None
         x_cap = None
@@ -455,7 +494,7 @@ class Engine(object):
             if pl is None:
                 i16 = dict(dtype=torch.int16, device="cuda")
                 need_dg = self.train and x.needs_grad
-                pl = dict(desc=desc, w=w,
+                pl = dict(desc=desc, w=w, fmt=fmt,
                           fwd_hi=torch.zeros((k * k, s.cout, s.cin), **i16), fwd_lo=torch.zeros((k * k, s.cout, s.cin), **i16),
                           dg_hi=torch.zeros((k * k, s.cin, _ru(s.cout, 32)), **i16) if need_dg else None,
                           dg_lo=torch.zeros((k * k, s.cin, _ru(s.cout, 32)), **i16) if need_dg else None)
@@ -604,7 +643,7 @@ class Engine(object):
         by_name = {o.name: o for o in self.fwd_ops}
         for k, name in enumerate(names):
             op = by_name[name]
-            octx = self.ctxs[op.lane]
+            octx = self.ctxs[op.lane].twin(self._fmt(op.name))
 
             def fn(inner=op.fn, k=k, octx=octx):
                 if self._sparse_fwd_now:
@@ -631,7 +670,7 @@ class Engine(object):
         d.kw = 1  # 7 kernel rows x (7 taps x 4 channels -> 32)
         self._stem = dict(desc=d, w=torch.zeros((7 * 32, _ru(s.cout, 16)), dtype=torch.float32, device="cuda"),
                           hi=torch.zeros((7, s.cout, 32), **i16), lo=torch.zeros((7, s.cout, 32), **i16))
-        ctx = self.ctxs[self._lane]
+        ctx = self.ctxs[self._lane].twin(self._fmt("conv1"))
         bias = self.params.view(self.params.w_eff, "conv1/bias")
         st = self._stem
         flops = 2.0 * y.rows * 49 * 3 * s.cout
@@ -646,7 +685,7 @@ class Engine(object):
         st["w"].zero_()
         for ty in range(7):
             st["w"][ty * 32: ty * 32 + 28] = w[ty * 28: (ty + 1) * 28]
-        ops.conv_split_weights3(self.ctx, st["desc"], st["w"], st["hi"], st["lo"], None, None)
+        ops.conv_split_weights3(self.ctx.twin(self._fmt("conv1")), st["desc"], st["w"], st["hi"], st["lo"], None, None)
 
     def _pyramid_buffer(self, level_shapes):
         """P3 | P4 | ... rows in one buffer, so that the shared heads run as ONE multi-level launch"""
@@ -685,7 +724,7 @@ class Engine(object):
             F5 = self._add("fpn_fin5", [D4, L5])
             P5 = self._conv("P5", F5, out_t=sl[2], out_pl=spl[2])
         needs = self.train
-        pyr = self._new_act("pyramid", lv, 256, 256, needs, False, pyr_t, pyr_pl, pyr_pl is not None)
+        pyr = self._new_act("pyramid", lv, 256, 256, needs, False, pyr_t, pyr_pl, pyr_pl is not None, fmt=P3.fmt)
         pyr.producer = getattr(P3, "producer", None)
         pyr.prod_ops = [o for part in (P3, P4, P5) for o in part.prod_ops]
         self.graph_ops.append(dict(kind="alias", y=pyr, parts=[P3, P4, P5], rows=rows))
@@ -712,16 +751,16 @@ class Engine(object):
             R6 = self._relu("P6_relu", P6)                                      # :154
             P7 = self._conv("P7_con", R6, out_t=sl[4], out_pl=spl[4])           # :155
             parts += [P6, P7]
-        pyr = self._new_act("pyramid", lv, 256, 256, self.train, False, pyr_t, pyr_pl, pyr_pl is not None)
+        pyr = self._new_act("pyramid", lv, 256, 256, self.train, False, pyr_t, pyr_pl, pyr_pl is not None, fmt=P3.fmt)
         pyr.producer = getattr(P3, "producer", None)
         pyr.prod_ops = [o for part in parts for o in part.prod_ops]
         self.graph_ops.append(dict(kind="alias", y=pyr, parts=parts, rows=rows))
         return pyr, P3
 
     def _relu(self, name, x):
-        out = self._new_act(name, x.shapes, x.C, x.ld, x.needs_grad, True, planes=self.po)
+        out = self._new_act(name, x.shapes, x.C, x.ld, x.needs_grad, True, planes=self.po, fmt=x.fmt)
         lane = self._lane
-        ctx = self.ctxs[lane]
+        ctx = self.ctxs[lane].twin(x.fmt)
         vx, vo = x.view(), out.view()
         self._push(Op(lambda: ops.relu_fwd_v(ctx, vx, vo), "pointwise", name, lane=lane), (x,), out)
         self.graph_ops.append(dict(kind="relu", y=out, x=x))
@@ -729,9 +768,10 @@ class Engine(object):
 
     def _upadd(self, name, src, other):
         (sh, sw), (th, tw) = src.shapes[0], other.shapes[0]
-        out = self._new_act(name, [(th, tw)], src.C, src.ld, src.needs_grad or other.needs_grad, planes=self.po)
+        other = self._convert(other, src.fmt)
+        out = self._new_act(name, [(th, tw)], src.C, src.ld, src.needs_grad or other.needs_grad, planes=self.po, fmt=src.fmt)
         lane, B = self._lane, self.B
-        ctx = self.ctxs[lane]
+        ctx = self.ctxs[lane].twin(src.fmt)
         vs, vt, vo = src.view(), other.view(), out.view()
         self._push(Op(lambda: ops.upsample_add_fwd_v(ctx, B, sh, sw, th, tw, src.C, vs, vt, vo), "pointwise", name, lane=lane),
                    (src, other), out)
@@ -739,9 +779,10 @@ class Engine(object):
         return out
 
     def _add(self, name, ins):
-        out = self._new_act(name, ins[0].shapes, ins[0].C, ins[0].ld, any(i.needs_grad for i in ins), planes=self.po)
+        ins = [ins[0]] + [self._convert(i, ins[0].fmt) for i in ins[1:]]
+        out = self._new_act(name, ins[0].shapes, ins[0].C, ins[0].ld, any(i.needs_grad for i in ins), planes=self.po, fmt=ins[0].fmt)
         lane = self._lane
-        ctx = self.ctxs[lane]
+        ctx = self.ctxs[lane].twin(ins[0].fmt)
         va, vb, vc = ins[0].view(), ins[1].view(), (ins[2].view() if len(ins) > 2 else None)
         vo = out.view()
         self._push(Op(lambda: ops.add_n_v(ctx, va, vb, vc, vo), "pointwise", name, lane=lane), ins, out)
@@ -749,25 +790,28 @@ class Engine(object):
         return out
 
     # ------------------------------------------------------------------------------------ backward plan
-    def _new_grad(self, rows, ld):
-        """an uninitialised gradient matrix in the mode's storage format"""
+    def _new_grad(self, rows, ld, fmt=0):
+        """an uninitialised gradient matrix in the mode's storage format (fmt: the plane format of the tensor it belongs to)"""
         if self.po and ld % 8 == 0:
-            return Grad(None, _new_planes(rows, ld))
+            return Grad(None, _new_planes(rows, ld), fmt)
         return Grad(torch.empty((rows, ld), dtype=torch.float32, device="cuda"))
 
     def _finalize(self, act):
         """Sum the gradient contributions of `act`; the ReLU mask (act > 0) is folded into the last
         data-gradient launch.  Returns the gradient w.r.t. the pre-activation (a Grad), or None."""
-        ctx = self.ctx
-        grads = [c[1] for c in act.contribs if c[0] == "tensor"]
+        ctx = self.ctx.twin(act.fmt)  # (every contribution to a tensor is in that tensor's plane format: its consumers read it so)
+        grads = [c[1] for c in act.contribs if c[0] in ("tensor", "masked")]  # masked: the ReLU of `act` is already applied
         dgrads = [c for c in act.contribs if c[0] == "dgrad"]
+        if any(c[0] == "masked" for c in act.contribs):
+            assert len(act.contribs) == 1, act.name
+            return grads[0]
         if not grads and not dgrads:
             return None
         acc = None
         if len(grads) == 1:
             acc = grads[0]
         elif len(grads) > 1:
-            acc = self._new_grad(act.rows, act.ld)
+            acc = self._new_grad(act.rows, act.ld, act.fmt)
             srcs, rest = grads[:3], grads[3:]
             while True:
                 va, vb, vc = srcs[0].view(), (srcs[1].view() if len(srcs) > 1 else None), (srcs[2].view() if len(srcs) > 2 else None)
@@ -791,7 +835,7 @@ class Engine(object):
                 # the rows no non-zero reaches keep their value and nothing else is moved (`acc` of i > 0 is private to this loop)
                 in_place = (sk is not None and i > 0 and mask is None and acc is not None and gcap is None
                             and _os.environ.get("PP_SPARSE_INPLACE", "1") != "0")
-                out = acc if in_place else self._new_grad(act.rows, act.ld)
+                out = acc if in_place else self._new_grad(act.rows, act.ld, act.fmt)
                 # every operand in the format it exists in (planes where there is no float32 copy)
                 dy_t, dy_pl = (None, gy.pl) if gy.pl is not None else (gy.t, None)
                 a_t = a_pl = m_t = m_hi = None
@@ -826,11 +870,14 @@ class Engine(object):
         self.g_cls = torch.zeros((self.cls_out.rows, self.cls_out.ld), **f32)
         self.g_mask = torch.zeros((self.mask_out.rows, self.mask_out.ld), **f32)
         for out, gt in ((self.reg_out, self.g_reg), (self.cls_out, self.g_cls), (self.mask_out, self.g_mask)):
-            g = Grad(gt)
+            g = Grad(gt, None, out.fmt)
             if self.po and out.ld % 8 == 0:
-                # the loss kernels write float32; the head's last conv takes its dy (bwd-data, bwd-weight) from planes
+                # the loss kernels write float32; the head's last conv takes its dy (bwd-data, bwd-weight) from planes -- in the
+                # format of that conv, multiplied by the gradient scale where that format is P16
                 g.pl = _new_planes(out.rows, out.ld)
-                self.bwd_ops.append(Op(lambda gt=gt, pl=g.pl: ops.split_planes3(ctx, gt, pl[0], pl[1], self.gscale), "pointwise", "split:" + out.name))
+                sctx, sc = ctx.twin(out.fmt), (self.gscale if out.fmt == 1 else None)
+                self.bwd_ops.append(Op(lambda gt=gt, pl=g.pl, sctx=sctx, sc=sc: ops.split_planes3(sctx, gt, pl[0], pl[1], sc), "pointwise",
+                                       "split:" + out.name))
             out.contribs.append(("tensor", g))
         for op in reversed(self.graph_ops):
             kind = op["kind"]
@@ -842,19 +889,35 @@ class Engine(object):
             g = self._finalize(y)
             if g is None:
                 continue
+            if kind == "convert":
+                # the boundary of the two arithmetics, backwards: the gradient of the re-encoded copy (P16: carries 2^G) returns to
+                # the original tensor's format (bf16 pairs: unscaled), or the other way round
+                x = op["x"]
+                if x.needs_grad:
+                    gx = self._new_grad(x.rows, x.ld, x.fmt)
+                    assert g.pl is not None and gx.pl is not None, x.name
+                    sc, idx = (self.gscale, 1) if (g.fmt == 1 and x.fmt == 0) else ((self.gscale, 0) if (g.fmt == 0 and x.fmt == 1) else (None, 0))
+                    # a ReLU output that only this copy consumes (C5) has no data-gradient launch to carry its mask: it goes here
+                    lone = x.relu and not any(o is not op and o.get("kind") == "conv" and o.get("x") is x for o in self.graph_ops)
+                    mhi = x.pl[0] if lone else None
+                    self.bwd_ops.append(Op(lambda g=g, gx=gx, sc=sc, idx=idx, mhi=mhi: ops.convert_planes(ctx, g.pl, g.fmt, gx.pl, gx.fmt, sc, idx, mhi),
+                                           "pointwise", "convert_bwd:" + x.name))
+                    x.contribs.append(("masked" if lone else "tensor", gx))
+                continue
             if kind == "conv":
                 s, x = op["spec"], op["x"]
+                lctx = ctx.twin(y.fmt)  # the layer's format = its output's
                 if self._sparse_layer(s) and g.contiguous() and len(g.shape()) == 2:
                     nb = (g.shape()[0] + 31) // 32
                     skip = op["skip"] = (torch.zeros((2 * nb,), dtype=torch.uint8, device="cuda"),   # flags | bwd-data scratch
                                          torch.zeros((2 * (nb + 1),), dtype=torch.int32, device="cuda"))
                     cols = min((y.C + 3) // 4 * 4, g.shape()[1])
                     if g.t is not None:
-                        self.bwd_ops.append(Op(lambda gt=g.t, cols=cols, skip=skip: ops.row_block_list(ctx, gt, cols, skip[0], skip[1]),
+                        self.bwd_ops.append(Op(lambda gt=g.t, cols=cols, skip=skip, lctx=lctx: ops.row_block_list(lctx, gt, cols, skip[0], skip[1]),
                                                "pointwise", "rowblocks:" + s.name))
                     else:
-                        self.bwd_ops.append(Op(lambda gp=g.pl, cols=cols, skip=skip, within=g.within:
-                                               ops.row_block_list_planes(ctx, gp, cols, skip[0], skip[1], within),
+                        self.bwd_ops.append(Op(lambda gp=g.pl, cols=cols, skip=skip, within=g.within, lctx=lctx:
+                                               ops.row_block_list_planes(lctx, gp, cols, skip[0], skip[1], within),
                                                "pointwise", "rowblocks:" + s.name))
                 if s.trainable:
                     dw = P.view(P.grad, s.name + "/kernel")
@@ -863,7 +926,7 @@ class Engine(object):
                     eb = P.entries[s.name + "/bias"]
                     wr = (ek["offset"], eb["offset"] + eb["count"])
                     wl = 1 % self.n_lanes
-                    wctx = self.ctxs[wl]
+                    wctx = self.ctxs[wl].twin(y.fmt)
                     pl_ = op.get("planes")
                     if (op.get("x_cap") is not None and x.needs_grad and pl_ is not None and pl_["dg_hi"] is not None
                             and g.pl is None and g.t.shape == (y.rows, y.ld) and g.t.is_contiguous()):
@@ -899,11 +962,12 @@ class Engine(object):
                 if other.needs_grad:
                     other.contribs.append(("tensor", g))
                 if src.needs_grad:
-                    gs = self._new_grad(src.rows, src.ld)
+                    gs = self._new_grad(src.rows, src.ld, src.fmt)
                     (sh, sw), (th, tw) = src.shapes[0], other.shapes[0]
                     vg, vs = g.view(), ops.tview(gs.t, gs.pl)
-                    self.bwd_ops.append(Op(lambda vg=vg, vs=vs, sh=sh, sw=sw, th=th, tw=tw, c=src.C:
-                                           ops.upsample_add_bwd_v(ctx, self.B, sh, sw, th, tw, c, vg, None, vs), "pointwise", "upbwd:" + src.name))
+                    uctx = ctx.twin(src.fmt)
+                    self.bwd_ops.append(Op(lambda vg=vg, vs=vs, sh=sh, sw=sw, th=th, tw=tw, c=src.C, uctx=uctx:
+                                           ops.upsample_add_bwd_v(uctx, self.B, sh, sw, th, tw, c, vg, None, vs), "pointwise", "upbwd:" + src.name))
                     src.contribs.append(("tensor", gs))
             elif kind == "relu":
                 # `g` already carries the mask (y > 0): _finalize folded it into the data-gradient launch that produced it
@@ -1093,13 +1157,17 @@ class Engine(object):
         key = "_split_trainable" if only_trainable else "_split_all"
         if not only_trainable and getattr(self, "stem3", False):
             self._refresh_stem()
-        batch = getattr(self, key, None)
-        if batch is None:
-            batch = ops.SplitWeightsBatch((pl["desc"], pl["w"], pl["fwd_hi"], pl["fwd_lo"], pl["dg_hi"], pl["dg_lo"])
-                                          for name, pl in self.planes.items()
-                                          if not only_trainable or self.params.specs[name].trainable)
-            setattr(self, key, batch)
-        batch.run(self.ctx)
+        batches = getattr(self, key, None)
+        if batches is None:  # one job table per plane format (the split kernel encodes in its context's format)
+            batches = []
+            for fmt in (0, 1):
+                jobs = [(pl["desc"], pl["w"], pl["fwd_hi"], pl["fwd_lo"], pl["dg_hi"], pl["dg_lo"]) for name, pl in self.planes.items()
+                        if pl.get("fmt", 0) == fmt and (not only_trainable or self.params.specs[name].trainable)]
+                if jobs:
+                    batches.append((fmt, ops.SplitWeightsBatch(jobs)))
+            setattr(self, key, batches)
+        for fmt, batch in batches:
+            batch.run(self.ctx.twin(fmt))
 
     def optimizer_step(self):
         P = self.params

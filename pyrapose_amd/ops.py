@@ -32,15 +32,40 @@ class Context:
         self.stream = s
         check(lib.pp_ctx_create(C.byref(self.handle), self.device, C.c_void_p(s.cuda_stream)), None, "pp_ctx_create")
 
+        self.planes_fmt = 0
+        self._twin = None
+
     def use_stream(self, stream):
         self.stream = stream
         check(lib.pp_ctx_set_stream(self.handle, C.c_void_p(stream.cuda_stream)), self.handle, "pp_ctx_set_stream")
+        if self._twin is not None:
+            self._twin.use_stream(stream)
+
+    def twin(self, fmt):
+        """This context for plane format `fmt` (0 bf16 pairs / bf16x3, 1 P16 / f16c8): itself, or -- created on first use -- a
+        second context on the same stream, with the same split-K scratch, whose launches read and write the other format."""
+        if int(fmt) == self.planes_fmt:
+            return self
+        if self._twin is None:
+            t = Context(self.device, self.stream)
+            set_planes_format(t, fmt)
+            t._twin = self
+            ws = getattr(self, "workspace", None)
+            t.workspace = ws
+            if ws is not None:
+                check(lib.pp_ctx_set_workspace(t.handle, _ptr(ws), ws.numel() * 4), t.handle, "pp_ctx_set_workspace")
+            self._twin = t
+        assert self._twin.planes_fmt == int(fmt)
+        return self._twin
 
     def set_workspace(self, nbytes):
         """Scratch for split-K convolutions (pp_ctx_set_workspace); 0 removes it."""
         self.workspace = torch.empty((int(nbytes) // 4,), dtype=torch.float32, device="cuda:%d" % self.device) if nbytes else None
-        check(lib.pp_ctx_set_workspace(self.handle, _ptr(self.workspace), (int(nbytes) // 4) * 4 if nbytes else 0), self.handle,
-              "pp_ctx_set_workspace")
+        for c in (self, self._twin):
+            if c is not None:
+                c.workspace = self.workspace
+                check(lib.pp_ctx_set_workspace(c.handle, _ptr(self.workspace), (int(nbytes) // 4) * 4 if nbytes else 0), c.handle,
+                      "pp_ctx_set_workspace")
 
     def device_info(self):
         n = C.c_int(0)
@@ -49,6 +74,10 @@ class Context:
         return n.value, buf.value.decode()
 
     def close(self):
+        t, self._twin = self._twin, None
+        if t is not None and t.handle:
+            t._twin = None
+            t.close()
         if self.handle:
             lib.pp_ctx_destroy(self.handle)
             self.handle = C.c_void_p()
@@ -126,17 +155,35 @@ def planes_ld(planes):
     return planes[0].stride(0) // 2
 
 
-def planes_to_f32(planes):
-    """value = hi + lo8 * 2^-12 as a float32 tensor [rows, ld] (torch arithmetic: tests / inspection).  hi = IEEE halves; the lo
-    unit of a gathered-operand tensor is [e5m2(hi) | e5m2(remainder * 2^12) << 8]: its high byte is the remainder."""
+def set_planes_format(ctx, fmt):
+    """0: bf16 pairs (bf16x3 arithmetic); 1: P16 (IEEE half + two e5m2 bytes; f16c8 arithmetic).  See pp_ctx_set_planes_format."""
+    check(lib.pp_ctx_set_planes_format(ctx.handle, int(fmt)), ctx.handle, "pp_ctx_set_planes_format")
+    ctx.planes_fmt = int(fmt)
+
+
+def convert_planes(ctx, src, src_fmt, dst, dst_fmt, scale2=None, scale_index=0, relu_src_hi=None):
+    """re-encode a plane pair into the other format (dst = src * scale2[scale_index] when scale2 is given; zero where the tensor
+    with hi plane relu_src_hi is not positive)"""
+    n = src[0].numel()
+    check(lib.pp_convert_planes(ctx.handle, n, _ptr(src[0]), _ptr(src[1]), int(src_fmt), _ptr(dst[0]), _ptr(dst[1]), int(dst_fmt), _ptr(scale2),
+                                int(scale_index), _ptr(relu_src_hi)), ctx.handle, "pp_convert_planes")
+
+
+def planes_to_f32(planes, fmt=0):
+    """the values of a plane pair as a float32 tensor [rows, ld] (torch arithmetic: tests / inspection).  fmt 0: bf16 pairs, hi + lo;
+    fmt 1 (P16): hi = IEEE halves, the lo unit of a gathered-operand tensor is [e5m2(x) | e5m2(remainder * 2^12) << 8]."""
     hi, lo = planes
     rows = hi.shape[0]
+    if fmt == 0:
+        return (hi.contiguous().view(torch.bfloat16).float() + lo.contiguous().view(torch.bfloat16).float()).reshape(rows, -1)
     rem = (lo.contiguous().to(torch.int32) & 0xff00).to(torch.int16).view(torch.float16).float() / 4096.0
     return (hi.contiguous().view(torch.float16).float() + rem).reshape(rows, -1)
 
 
-def weight_planes_to_f32(hi, lo):
-    """the same for weight planes (the lo unit's bytes are swapped: the remainder is its LOW byte)"""
+def weight_planes_to_f32(hi, lo, fmt=0):
+    """the same for weight planes (P16: the lo unit's bytes are swapped, the remainder is its LOW byte)"""
+    if fmt == 0:
+        return hi.contiguous().view(torch.bfloat16).float() + lo.contiguous().view(torch.bfloat16).float()
     rem = ((lo.contiguous().to(torch.int32) & 0xff) << 8).to(torch.int16).view(torch.float16).float() / 4096.0
     return hi.contiguous().view(torch.float16).float() + rem
 

@@ -180,12 +180,13 @@ def test_sparse_forward_of_box_head_is_exact_for_training(ctx, monkeypatch):
     # (one Adam step moves every weight by ~lr whatever the size of its gradient: where the two gradients are noise of opposite
     # sign the weights part by 2 lr -- that, not a relative bound, is the scale of an honest difference)
     assert float((wa - wb).abs().max()) <= 2.5 * 1e-4
-    # outside a training step nothing is skipped
+    # outside a training step nothing is skipped (the two weight sets have parted by up to 2 lr per weight in the fourth step, which
+    # moves the outputs by a few 1e-4 of their scale; a row block left out would show as O(1))
     a.forward(xs[0])
     b.forward(xs[0])
     torch.cuda.synchronize()
     ra, rb = a.reg_out.t[:, : a.reg_out.C], b.reg_out.t[:, : b.reg_out.C]
-    assert float((ra - rb).abs().max()) <= 2e-5 * float(ra.abs().max())
+    assert float((ra - rb).abs().max()) <= 2e-3 * float(ra.abs().max())
     a.close()
     b.close()
 
