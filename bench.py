@@ -34,19 +34,32 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (never the 2:1-sparsity figure
 ALGO_GFLOP_PER_IMAGE = {(13, 480, 640): 683.2}  # BASELINE.md §3 (fwd 234.2 + bwd 449.1)
 
 
+DTYPE_NOTES = {
+    "f32": "exact f32 MFMA (v_mfma_f32_32x32x2_f32) everywhere",
+    "bf16x3": "every conv product = x_hi*w_hi + x_hi*w_lo + x_lo*w_hi on bf16 MFMA with f32 accumulation (2^-16 relative); master weights, "
+              "losses and Adam in float32; head outputs within 1e-3 of the float64 oracle (tests/test_gpu_model.py, test_gpu_parity.py)",
+    "f16c8": "every conv product = x_hi*w_hi on f16 MFMA + (x_hi8*w_lo8 + x_lo8*w_hi8) * 2^-12 on block-scaled e5m2 MFMA, f32 accumulation "
+             "(2^-15 relative); gradients travel times a power of two; master weights, losses and Adam in float32",
+    "mixed": "NOT a reduced-precision number: float32-equivalent emulated products with f32 accumulation in both halves.  Backbone (conv1, "
+             "res2-res5): x_hi*w_hi + x_hi*w_lo + x_lo*w_hi on bf16 MFMA (2^-16 relative).  FPN + heads: x_hi*w_hi on f16 MFMA + both "
+             "cross terms on block-scaled e5m2 MFMA (2^-15 relative; gradients travel times a power of two).  Master weights, losses "
+             "and Adam in float32; head outputs and weight gradients within 1e-3 of the float64 oracle at full size "
+             "(tests/test_gpu_parity.py, test_gpu_model.py)",
+}
+
 EVENT_EVERY = 4  # per-launch HIP events on steps 0, 4, 8, ... of the timed region
 
 
-def measured_peak(mode, achieved):
+def measured_peak(mode, achieved):  # achieved: MFMA-unit TFLOP/s (executed flops x units per product)
     """the box-measured denominator next to the spec peak (profiles/r01_peaks.json, tools/ubench/peaks.hip)"""
     path = os.path.join(ROOT, "profiles", "r01_peaks.json")
-    if mode != "bf16x3" or not os.path.exists(path):
+    if mode == "f32" or not os.path.exists(path):
         return None
     with open(path) as f:
         pk = json.load(f)
     m = pk["bf16_mfma_tflops_with_lds_reads"]
     return {"bf16_mfma_tflops_sustained_random_data": pk["bf16_mfma_tflops_registers"], "with_lds_fragment_reads": m,
-            "mfma_issue_frac_of_measured": achieved * 3 / m, "source": "profiles/r01_peaks.json (tools/ubench/peaks.hip, 20 ms launches)"}
+            "mfma_issue_frac_of_measured": achieved / m, "source": "profiles/r01_peaks.json (tools/ubench/peaks.hip, 20 ms launches)"}
 
 
 def synth_batch(B, H, W, C, seed, side=(40, 160), boxes=None):
@@ -317,7 +330,8 @@ def parse_args(argv=None):
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--backbone", default="resnet50", choices=["resnet50", "resnet101"],
                     help="resnet101 = the [3,4,23,3] variant of BASELINE configs[4] (with --height 540 --width 720 --classes 30)")
-    ap.add_argument("--conv-mode", default=None, choices=["f32", "bf16x3"], help="default: env PP_CONV_MODE or bf16x3")
+    ap.add_argument("--conv-mode", default=None, choices=["f32", "bf16x3", "f16c8", "mixed"],
+                    help="arithmetic of the convolutions (engine.py): default env PP_CONV_MODE or mixed = bf16x3 backbone, f16c8 FPN + heads")
     ap.add_argument("--boxes-per-image", type=int, default=None,
                     help="objects per synthetic image (default: U{1..3}, SURVEY 8d config 2).  The sparse backward of the 3D-box head makes "
                          "`value` depend on the annotation density: LineMOD has 1 object per image, YCB-V / T-LESS 5-15")
@@ -434,6 +448,7 @@ def main_worker(args):
         for _ in range(warmup):
             eng.train_step(next_x=nx)
         records = []
+        units = {}  # MFMA issue slots per product of each conv layer: f32 1, bf16x3 3, f16c8 2 (csrc/planes_fmt.h)
         # per-launch events cost CPU time (the launch loop must stay ahead of the GPU): they are recorded on every
         # EVENT_EVERY-th timed step only, from pools created before the timed region
         sample = [-1]  # index of the sampled step, or -1
@@ -453,6 +468,8 @@ def main_worker(args):
                     inner()
                     e.record(st)
                     records.append((op.kind, op.name, op.flops, s, e))
+                units[op.name] = 1 if eng.conv_mode == "f32" else (2 if eng._fmt(op.name) == 1 else 3)
+
                 op.fn = fn
             for op in eng.fwd_ops + eng.bwd_ops:
                 if op.kind in ("conv_fwd", "conv_dgrad", "conv_wgrad"):
@@ -480,7 +497,7 @@ def main_worker(args):
             # algorithmic flops / length of the UNION of the launch intervals (time during which >= 1 conv kernel
             # ran); per-kernel figures use each launch's own event-bracketed interval (inflated where launches overlap).
             agg, spans = {}, []
-            dense_flops = 0.0
+            dense_flops = unit_flops = 0.0
             for kind, name, flops, s_ev, e_ev in records:
                 t_s, t_e = base_ev.elapsed_time(s_ev) * 1e-3, base_ev.elapsed_time(e_ev) * 1e-3
                 spans.append((t_s, t_e))
@@ -492,6 +509,7 @@ def main_worker(args):
                 a[0] += flops
                 a[1] += t_e - t_s
                 a[2] += 1
+                unit_flops += flops * units[name]
             spans.sort()
             union, cur_s, cur_e = 0.0, spans[0][0], spans[0][1]
             for t_s, t_e in spans[1:]:
@@ -509,12 +527,13 @@ def main_worker(args):
                 b[1] += s_ev.elapsed_time(e_ev) * 1e-3
                 b[2] += 1
             (bk, bn), (bfl, bsec, bcnt) = max(((k, v) for k, v in big.items() if k[0] == "conv_fwd"), key=lambda kv: kv[1][0])
-            largest = {"launch": "%s %s" % (bk, bn), "gflop": bfl / 1e9, "avg_us": 1e6 * bsec / bcnt, "tflops": bfl / (bsec / bcnt) / 1e12}
+            largest = {"launch": "%s %s" % (bk, bn), "gflop": bfl / 1e9, "avg_us": 1e6 * bsec / bcnt, "tflops": bfl / (bsec / bcnt) / 1e12,
+                       "units": units[bn]}
             names = {"conv_fwd": "igemm fwd", "conv_dgrad": "igemm bwd-data", "conv_wgrad": "wgrad"}
             kernels = [{"kernel": names[k], "launches": n, "avg_ms": 1e3 * sec / n, "tflops_own_interval": fl / sec / 1e12}
                        for k, (fl, sec, n) in agg.items()]
             fl = sum(v[0] for v in agg.values())
-            roof = {"achieved": dense_flops / union / 1e12, "executed": fl / union / 1e12, "sparse": sp_frac,
+            roof = {"achieved": dense_flops / union / 1e12, "executed": fl / union / 1e12, "executed_units": unit_flops / union / 1e12, "sparse": sp_frac,
                     "conv_share_of_step": union / (dt * n_sampled / steps), "lanes": eng.n_lanes,
                     "sampled_steps": n_sampled, "largest_launch": largest,
                     "dominant": max(agg.items(), key=lambda kv: kv[1][1])[0], "per_kernel": kernels}
@@ -532,7 +551,7 @@ def main_worker(args):
                     for key in order:
                         fl_, sec, n = per[key]
                         f.write("%s,%s,%.3f,%.1f,%.1f\n" % (key[0], key[1], fl_ / 1e9, 1e6 * sec / n, fl_ / (sec / n) / 1e12))
-        mode_used = eng.conv_mode
+        mode_used = "f32" if eng.conv_mode == "f32" else eng.arith  # the arithmetic that ran: f32 | bf16x3 | f16c8 | mixed
         if roof is None and sp_frac:
             roof = {"sparse": sp_frac}
         del eng
@@ -562,19 +581,27 @@ def main_worker(args):
                 tj = json.load(f)
             traffic = tj.get(mode)
             if traffic is not None:
-                src = os.path.join(ROOT, "pyrapose_amd", "csrc", "conv3.hip" if mode == "bf16x3" else "conv.hip")
-                try:
-                    with open(src, "rb") as f:
-                        now = hashlib.sha256(f.read()).hexdigest()[:16]
+                try:  # (the plane-format kernels = conv3.hip + the arithmetic header it is compiled against)
+                    hsh = hashlib.sha256()
+                    for src in (["conv.hip"] if mode == "f32" else ["conv3.hip", "planes_fmt.h", "p16.h"]):
+                        with open(os.path.join(ROOT, "pyrapose_amd", "csrc", src), "rb") as f:
+                            hsh.update(f.read())
+                    now = hsh.hexdigest()[:16]
                 except OSError:
                     now = None
                 traffic = dict(traffic, file=os.path.relpath(tfiles[-1], ROOT), kernel_source_sha16_now=now,
                                stale=(traffic.get("kernel_source_sha16") != now))
-        if mode == "bf16x3":
-            peak, kname = PEAK_BF16_MFMA_TFLOPS, "conv implicit-GEMM family (igemm3x / igemm3f fwd + bwd-data, wgrad3f): 3 x v_mfma_f32_32x32x16_bf16 per product, f32 accumulate"
+        if mode != "f32":
+            peak = PEAK_BF16_MFMA_TFLOPS  # (dense f16 = dense bf16 = 2.5 PFLOP/s; the e5m2 cross terms are priced in f16-MFMA units, below)
+            kname = {"bf16x3": "conv implicit-GEMM family (igemm3x / igemm3f fwd + bwd-data, wgrad3f): 3 x v_mfma_f32_32x32x16_bf16 per product, f32 accumulate",
+                     "f16c8": "conv implicit-GEMM family (igemm3x / igemm3f fwd + bwd-data, wgrad3f) on P16 planes: per 32-deep step 2 x "
+                              "v_mfma_f32_32x32x16_f16 + 1 x v_mfma_scale_f32_32x32x64_f8f6f4 (e5m2 cross terms) = 2 MFMA units per product"}.get(
+                mode, "conv implicit-GEMM family (igemm3x / igemm3f fwd + bwd-data, wgrad3f), one source compiled per plane format: backbone = "
+                      "3 x v_mfma_f32_32x32x16_bf16 per product (bf16x3); FPN + heads = v_mfma_f32_32x32x16_f16 + half a "
+                      "v_mfma_scale_f32_32x32x64_f8f6f4 per 16-deep step (f16c8: 2 MFMA units per product)")
         else:
             peak, kname = PEAK_F32_MFMA_TFLOPS, "conv implicit-GEMM family (igemm fwd/bwd-data + wgrad): v_mfma_f32_32x32x2_f32"
-        mm = 3 if mode == "bf16x3" else 1
+        mm = roof["executed_units"] / roof["executed"]  # MFMA issue slots (16-deep f16/bf16 MFMA equivalents) per executed product
         roofline = {"bound": "mfma", "achieved": roof["executed"], "peak": peak, "unit": "TFLOP/s", "frac": roof["executed"] / peak,
                     "achieved_algorithmic": roof["achieved"], "frac_algorithmic": roof["achieved"] / peak,
                     "traffic": (traffic or {}).get("hbm_bytes_per_launch"), "traffic_detail": traffic, "kernel": kname,
@@ -588,20 +615,23 @@ def main_worker(args):
                     "mfma_flops_per_algorithmic_flop": mm,
                     "mfma_issue_frac": roof["executed"] * mm / peak,
                     "vs_f32_mfma_peak_157.3": roof["executed"] / PEAK_F32_MFMA_TFLOPS,
-                    "measured_peak": measured_peak(mode, roof["executed"]),
+                    "measured_peak": measured_peak(mode, roof["executed_units"]),
                     "dominant": roof["dominant"], "conv_share_of_step": roof["conv_share_of_step"], "lanes": roof["lanes"],
                     "largest_launch": dict(roof["largest_launch"], frac=roof["largest_launch"]["tflops"] / peak,
-                                           mfma_issue_frac=roof["largest_launch"]["tflops"] * mm / peak),
+                                           mfma_issue_frac=roof["largest_launch"]["tflops"] * roof["largest_launch"]["units"] / peak),
                     "per_kernel": roof["per_kernel"]}
 
     other = None
     if world == 1 and not args.no_alt_mode:
-        alt = "f32" if mode == "bf16x3" else "bf16x3"
-        dt2, img2, losses2, roof2, _ = run(alt, max(3, args.steps // 2), 2, True)
-        pk = PEAK_F32_MFMA_TFLOPS if alt == "f32" else PEAK_BF16_MFMA_TFLOPS
-        other = {"conv_mode": alt, "value": img2 / dt2, "unit": "images/sec", "ms_per_step": 1e3 * dt2 / max(3, args.steps // 2),
-                 "roofline_achieved_tflops": roof2["achieved"] if roof2 else None, "roofline_peak": pk,
-                 "roofline_frac": (roof2["achieved"] / pk) if roof2 else None, "losses": losses2}
+        # the other arithmetics on the same box, same process (short runs): the exact f32 MFMA path, and -- when the step ran mixed --
+        # the all-bf16x3 step it replaced (3 MFMA units per product everywhere)
+        other = []
+        for alt in (["f32"] if mode == "bf16x3" else (["bf16x3"] if mode == "f32" else ["bf16x3", "f32"])):
+            dt2, img2, losses2, roof2, _ = run(alt, max(3, args.steps // 2), 2, True)
+            pk = PEAK_F32_MFMA_TFLOPS if alt == "f32" else PEAK_BF16_MFMA_TFLOPS
+            other.append({"conv_mode": alt, "value": img2 / dt2, "unit": "images/sec", "ms_per_step": 1e3 * dt2 / max(3, args.steps // 2),
+                          "roofline_achieved_tflops": roof2["achieved"] if roof2 else None, "roofline_peak": pk,
+                          "roofline_frac": (roof2["achieved"] / pk) if roof2 else None, "losses": losses2})
 
     sparse = None
     if roof and roof.get("sparse"):
@@ -613,7 +643,7 @@ def main_worker(args):
         if world == 1 and not args.no_alt_mode:
             dt3, img3, _, _, _ = run(mode, max(3, args.steps // 2), 2, False, sparse="0")
             sparse["dense_backward"] = {"value": img3 / dt3, "unit": "images/sec", "ms_per_step": 1e3 * dt3 / max(3, args.steps // 2)}
-            if mode == "bf16x3" and os.environ.get("PP_SPARSE_FWD", "0") != "1":
+            if mode != "f32" and os.environ.get("PP_SPARSE_FWD", "0") != "1":
                 # NOT part of `value`: the opt-in PP_SPARSE_FWD=1 also skips, in the FORWARD pass of a training step, the rows of the
                 # 3D-box head that its loss never reads (dead outputs in train_on_batch; losses / gradients / weights unchanged,
                 # tests/test_gpu_pipeline.py) -- reported so that the number exists, kept out of the headline because the skipped
@@ -640,13 +670,11 @@ def main_worker(args):
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "rccl_ranks": (world if backend == "nccl" else 0), "dist_backend": backend,
         "value_dense_backward": ((sparse or {}).get("dense_backward") or {}).get("value"),
-        "dtype": "bf16x3" if mode == "bf16x3" else "f32", "data": "synthetic", "sparse_backward": sparse,
+        "dtype": {"mixed": "bf16x3+f16c8"}.get(mode, mode), "data": "synthetic", "sparse_backward": sparse,
         "pipeline": ("software-pipelined over steps: the frozen prefix (conv1 + res2, no trainable weight) of batch i+1 runs on its own "
                      "stream beside batch i; every step executes one prefix, one trunk + heads forward, one backward, one optimizer "
                      "update (--no-prefetch: everything of a batch inside its own step)") if prefetch_used else "none",
-        "dtype_note": ("every conv product = x_hi*w_hi + x_hi*w_lo + x_lo*w_hi on bf16 MFMA with f32 accumulation (2^-16 relative); "
-                       "activations, master weights, losses and Adam in float32; head outputs within 1e-3 of the float64 oracle "
-                       "(tests/test_gpu_model.py)") if mode == "bf16x3" else "exact f32 MFMA (v_mfma_f32_32x32x2_f32) everywhere",
+        "dtype_note": DTYPE_NOTES[mode],
         "config": {"workload": "%s %d-class training, batch %d/GPU, %dx%d, %s PFPN + heads (BASELINE configs[%s]), %s"
                                % ("LineMOD" if C == 13 else ("YCB-Video" if C == 21 else ("T-LESS" if C == 30 else "synthetic")), C, B, W, H,
                                   {"resnet50": "ResNet-50", "resnet101": "ResNet-101"}[args.backbone],
