@@ -244,9 +244,17 @@ def test_pointwise_ops(ctx):
 BF3_CASES = [c for c in CASES if c[3] % 32 == 0 and c[4] % 32 == 0]
 
 
+@pytest.fixture(scope="module", params=[0, 1], ids=["bf16x3", "f16c8"])
+def pctx(ctx, request):
+    """the context once per plane format / arithmetic of the *_bf16x3 entry points (csrc/planes_fmt.h): bf16 pairs (three bf16
+    MFMAs per product), and P16 (f16 MFMA + block-scaled e5m2 cross terms)"""
+    return ctx.twin(request.param)
+
+
 @pytest.mark.parametrize("case", BF3_CASES, ids=[c[0] for c in BF3_CASES])
-def test_conv_bf16x3_fwd_bwd_data(ctx, case):
+def test_conv_bf16x3_fwd_bwd_data(pctx, case):
     """3 x bf16 MFMA path: float32-class accuracy (<= 1e-4 of the output magnitude, ~2^-16 per product)."""
+    ctx = pctx
     from pyrapose_amd import ops
     name, B, shapes, cin, cout, k, stride, pad, ld_y, xs, w, bias = _setup(case, seed=3)
     ref = ref_conv(xs, w, bias, stride, pad)
@@ -265,9 +273,9 @@ def test_conv_bf16x3_fwd_bwd_data(ctx, case):
     dh, dl = torch.zeros((taps, cin, cout), **u16), torch.zeros((taps, cin, cout), **u16)
     ops.conv_split_weights3(ctx, d, wd, fh, fl, dh, dl)
     # the planes reproduce the weights to 2^-15 (half + e5m2 remainder)
-    back = ops.weight_planes_to_f32(fh, fl).permute(0, 2, 1).reshape(taps * cin, cout).cpu().numpy()
+    back = ops.weight_planes_to_f32(fh, fl, ctx.planes_fmt).permute(0, 2, 1).reshape(taps * cin, cout).cpu().numpy()
     assert rel_err(back, w.reshape(-1, cout)) < 3.1e-5
-    back = ops.weight_planes_to_f32(dh, dl).reshape(taps * cin, cout).cpu().numpy()
+    back = ops.weight_planes_to_f32(dh, dl, ctx.planes_fmt).reshape(taps * cin, cout).cpu().numpy()
     assert rel_err(back, w.reshape(-1, cout)) < 3.1e-5
     rows_out = sum(B * h * ww for h, ww in out_shapes)
     rng = np.random.default_rng(1)
@@ -283,7 +291,7 @@ def test_conv_bf16x3_fwd_bwd_data(ctx, case):
     # kernel (tap order), so equal up to f32 summation order
     xh, xl = ops.new_planes(x.shape[0], x.shape[1])
     ops.split_planes3(ctx, x, xh, xl)
-    assert rel_err(ops.planes_to_f32((xh, xl)).cpu().numpy(), x.cpu().numpy()) < 3.1e-5
+    assert rel_err(ops.planes_to_f32((xh, xl), ctx.planes_fmt).cpu().numpy(), x.cpu().numpy()) < 3.1e-5
     y2 = torch.full_like(y, float("nan"))
     yh, yl = ops.new_planes(y.shape[0], y.shape[1])
     ops.conv_fwd3(ctx, d, None, fh, fl, bd.cuda(), _cat_rows(res, ld_y), True, y2, x_planes=(xh, xl), y_planes=(yh, yl))
@@ -346,8 +354,9 @@ WG3_CASES = [c for c in CASES if c[3] % 64 == 0]
 
 
 @pytest.mark.parametrize("case", WG3_CASES, ids=[c[0] for c in WG3_CASES])
-def test_conv_bf16x3_bwd_weight(ctx, case):
+def test_conv_bf16x3_bwd_weight(pctx, case):
     """Weight gradient on the bf16 matrix cores (transposed LDS reads) vs float64 autograd."""
+    ctx = pctx
     from pyrapose_amd import ops
     name, B, shapes, cin, cout, k, stride, pad, ld_y, xs, w, bias = _setup(case, seed=5)
     xg = [t.clone() for t in xs]
@@ -392,8 +401,9 @@ def test_conv_bf16x3_bwd_weight(ctx, case):
     assert rel_err(db2.cpu().numpy()[:cout], db_ref) < 5e-5
 
 
-def test_split_weights_batch_matches_per_tensor(ctx):
+def test_split_weights_batch_matches_per_tensor(pctx):
     """pp_conv_split_weights_bf16x3_batch: one launch over several tensors == the per-tensor launches, bit for bit."""
+    ctx = pctx
     from pyrapose_amd import ops
     rng = np.random.default_rng(5)
     jobs, want = [], []
@@ -421,9 +431,10 @@ def test_split_weights_batch_matches_per_tensor(ctx):
 
 
 @pytest.mark.parametrize("splits", [2, 5])
-def test_conv_bf16x3_split_k(ctx, splits, monkeypatch):
+def test_conv_bf16x3_split_k(pctx, splits, monkeypatch):
     """Split-K (pp_ctx_set_workspace): same result as the single-pass launch up to f32 summation order, both directions,
     fused bias / residual / mask / ReLU applied by the finishing pass; deterministic (two runs are bit-identical)."""
+    ctx = pctx
     from pyrapose_amd import ops
     rng = np.random.default_rng(11)
     B, H, W, cin, cout, k = 2, 9, 13, 128, 80, 3
@@ -475,9 +486,10 @@ def test_conv_bf16x3_split_k(ctx, splits, monkeypatch):
 
 
 @pytest.mark.parametrize("frac", [0.0, 0.03, 1.0])
-def test_row_block_skip_matches_dense(ctx, frac):
+def test_row_block_skip_matches_dense(pctx, frac):
     """Sparse gradients (3D-box head: non-zero only around positive anchors): bwd-weight over the listed 32-row blocks of dy
     and bwd-data with tile skipping give the dense results -- a block of zero rows adds exactly 0.0."""
+    ctx = pctx
     from pyrapose_amd import ops
     rng = np.random.default_rng(17)
     B, shapes, cin, cout, k = 2, [(20, 26), (10, 13), (5, 7)], 128, 64, 3

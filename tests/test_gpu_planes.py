@@ -13,8 +13,19 @@ from tests.test_gpu_conv import BF3_CASES, WG3_CASES, _cat_rows, _device_weight,
 pytestmark = pytest.mark.gpu
 
 
+FMT = [0]  # plane format of the context the running test got (merged() / split() decode with it)
+
+
+@pytest.fixture(scope="module", params=[0, 1], ids=["bf16x3", "f16c8"])
+def ctx(request):
+    """every test of this module once per plane format / arithmetic (csrc/planes_fmt.h): bf16 pairs, and P16"""
+    from pyrapose_amd.runtime import default_context
+    FMT[0] = request.param
+    return default_context().twin(request.param)
+
+
 @pytest.fixture(scope="module")
-def ctx():
+def ectx():
     from pyrapose_amd.runtime import default_context
     return default_context()
 
@@ -28,7 +39,7 @@ def split(ctx, t):
 
 def merged(pl):
     from pyrapose_amd import ops
-    return ops.planes_to_f32(pl)
+    return ops.planes_to_f32(pl, FMT[0])
 
 
 def nan_planes(like):
@@ -332,7 +343,7 @@ def test_pointwise_ops_on_views(ctx):
 
 
 @pytest.mark.parametrize("mode", ["1", "0"])
-def test_engine_planes_mode_matches_f32_storage(ctx, mode, monkeypatch):
+def test_engine_planes_mode_matches_f32_storage(ectx, mode, monkeypatch):
     """The whole training step with planes-only storage (default) vs float32 storage with in-loop splits (PP_PLANES=0): same
     products; residual / addend reads differ by 2^-15 -> every output agrees to ~1e-4."""
     from pyrapose_amd import arch
@@ -343,7 +354,7 @@ def test_engine_planes_mode_matches_f32_storage(ctx, mode, monkeypatch):
     Wt = arch.init_weights(C, seed=72)
     x = torch.from_numpy(synth_input(rng, B, H, W)).cuda()
     monkeypatch.setenv("PP_PLANES", mode)
-    eng = Engine(ctx, C, B, H, W, weights=Wt, train=True, conv_mode="bf16x3")
+    eng = Engine(ectx, C, B, H, W, weights=Wt, train=True, conv_mode="bf16x3")
     assert eng.po == (mode == "1")
     if mode == "1":
         assert eng.C3.t is None and eng.C3.pl is not None and eng.pyr.t is None and eng.reg_out.t is not None

@@ -58,8 +58,12 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--mode", default="fwd,dgrad,wgrad")
     ap.add_argument("--check", action="store_true", help="print the error of the forward modes against a float64 convolution")
+    ap.add_argument("--fmt", type=int, default=0, choices=[0, 1],
+                    help="plane format / arithmetic of the *3* modes: 0 = bf16 pairs (bf16x3), 1 = P16 (f16c8)")
     args = ap.parse_args()
     ctx = ops.Context(0)
+    if args.fmt:
+        ops.set_planes_format(ctx, args.fmt)
     if os.environ.get("PP_SPLITK_MB"):
         ctx.set_workspace(int(os.environ["PP_SPLITK_MB"]) << 20)
     for name in args.shape.split(","):
