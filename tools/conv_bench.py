@@ -67,6 +67,9 @@ def main():
     if os.environ.get("PP_SPLITK_MB"):
         ctx.set_workspace(int(os.environ["PP_SPLITK_MB"]) << 20)
     for name in args.shape.split(","):
+        if name.startswith("c:"):  # c:B:H:W:cin:cout:k -- one level, stride 1, "same" padding (tile-count experiments)
+            B_, H_, W_, ci_, co_, k_ = [int(v) for v in name[2:].split(":")]
+            SHAPES[name] = (B_, [(H_, W_)], ci_, co_, k_, 1, k_ // 2)
         B, shapes, cin, cout, k, stride, pad = SHAPES[name]
         rows_in = sum(B * h * w for h, w in shapes)
         out_shapes = [(-(-h // stride), -(-w // stride)) for h, w in shapes]
