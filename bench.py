@@ -211,7 +211,8 @@ def inference_leg(ctx, mode, B=32, C=8, H=480, W=640, steps=6, warmup=2):
                                                                  "anchors_per_sec": B * N * 1e3 / ms}
     res.update({"workload": "Occlusion-style inference, batch %d, %d classes, %dx%d, forward + anchors + box3D decode + score>0.5 "
                             "compaction [+ filter_detections] (BASELINE configs[2])" % (B, C, W, H),
-                "frac_scores_over_0.5": float((scores > 0.5).float().mean()), "steps": steps, "warmup": warmup, "dtype": eng.conv_mode,
+                "frac_scores_over_0.5": float((scores > 0.5).float().mean()), "steps": steps, "warmup": warmup,
+                "dtype": "f32" if eng.conv_mode == "f32" else {"mixed": "bf16x3+f16c8"}.get(eng.arith, eng.arith),
                 "n_gpus": 1, "data": "synthetic"})
     del eng
     torch.cuda.empty_cache()
