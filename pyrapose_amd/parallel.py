@@ -113,7 +113,6 @@ class DataParallel(object):
             self.by_op.setdefault(r, []).append((a, b))
         self.flat = engine.params.grad
         self.on_gpu = self.flat.is_cuda
-        self.comm_stream = torch.cuda.Stream() if self.on_gpu else None
         self.works = []
         engine.grad_sync = self
 
@@ -126,10 +125,10 @@ class DataParallel(object):
         if not self.active:
             return
         if self.on_gpu:
-            ev = torch.cuda.Event()
-            ev.record(stream if stream is not None else torch.cuda.current_stream())
-            self.comm_stream.wait_event(ev)
-            with torch.cuda.stream(self.comm_stream):
+            # the process group enqueues the collective on ITS OWN stream, ordered after the stream that is current at the call:
+            # making the producing lane current is all the ordering there is to do (no event, no communication stream of ours --
+            # one HIP stream fewer per rank: streams beyond the hardware queues of a process alias and serialise)
+            with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream()):
                 self.works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)

@@ -29,7 +29,7 @@ for it in range(4):
     dp.finish(); sync(); t3 = time.perf_counter()
     eng.optimizer_step(); sync(); t4 = time.perf_counter()
     if rank == 0:
-        print("it %d lanes %d: fwd %.1f  bwd(+launch allreduce) %.1f  finish %.1f  opt %.1f ms; streams %s comm %s" % (
+        print("it %d lanes %d: fwd %.1f  bwd(+launch allreduce) %.1f  finish %.1f  opt %.1f ms; streams %s" % (
             it, eng.n_lanes, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3,
-            [hex(s.cuda_stream) for s in eng.streams], hex(dp.comm_stream.cuda_stream)), flush=True)
+            [hex(s.cuda_stream) for s in eng.streams]), flush=True)
 dist.destroy_process_group()
