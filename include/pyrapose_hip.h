@@ -82,6 +82,14 @@ int pp_row_block_list_planes_within(pp_ctx* ctx, const void* x_hi, const void* x
  * hi plane is read (hi > 0 <=> value > 0).  Any of the three may be NULL (add_hi and add_lo go together). */
 int pp_ctx_set_epilogue_planes(pp_ctx* ctx, const void* add_hi, const void* add_lo, const void* mask_hi);
 int pp_ctx_set_row_block_skip(pp_ctx* ctx, const unsigned char* flags, const int* list);
+/* Lazy sparse gradients (one-shot, for the NEXT bwd-data / bwd-weight call on this context, beside pp_ctx_set_row_block_skip).
+ * lazy_out: a bwd-data call that runs the listed-block launch leaves the rows of dx outside the blocks it computes UNTOUCHED instead
+ * of writing mask?(addend or 0) to them -- legitimate when every reader of that dx goes by flags: a scan restricted to the computed
+ * blocks (pp_row_block_list_planes_within with the second half of this call's flags), a listed-block bwd-weight, a listed-block
+ * bwd-data (whose gather never fetches a row outside the flagged blocks of its dy).  lazy_in: the dy of the call is such a tensor;
+ * the call FAILS (PP_ERR_ARG) instead of running a launch that would read the unwritten rows.  The 3D-box head's backward uses
+ * both: four fill passes of 103 MB per training step are not made. */
+int pp_ctx_set_row_block_lazy(pp_ctx* ctx, int lazy_out, int lazy_in);
 const char* pp_last_error_string(pp_ctx* ctx);
 const char* pp_version(void);
 /* number of compute units / name of the device the ctx is bound to (for bench metadata) */

@@ -104,6 +104,7 @@ _SIGS = {
     "pp_row_block_list": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "pp_ctx_set_row_block_skip": (_i, [_p, _p, _p]),
     "pp_ctx_set_row_block_out": (_i, [_p, _p, _p]),
+    "pp_ctx_set_row_block_lazy": (_i, [_p, _i, _i]),
     "pp_positive_row_blocks": (_i, [_p, _p, _i, _i, _p, _p]),
     "pp_row_block_dilate": (_i, [_p, _p, _p, _p]),
     "pp_row_block_list_planes": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),

@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
     const void* __restrict__ g_whi, const void* __restrict__ g_wlo, unsigned w_bytes,
     const float* __restrict__ g_bias, const float* __restrict__ g_addend, const float* __restrict__ g_mask,
     float* __restrict__ g_out, uint2* __restrict__ g_ohi, uint2* __restrict__ g_olo, int w_rows, int w_ld8, int splits,
-    float* __restrict__ g_ws, const int* __restrict__ g_rl = nullptr) {
+    float* __restrict__ g_ws, const int* __restrict__ g_rl = nullptr, const unsigned char* __restrict__ g_srcflags = nullptr) {
   constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, NO = BK / 8;
   constexpr int SMEM_U4 = 2 * NO * (BM + BN);
   constexpr int ES = 4;  // bytes per gathered element: f32, or packed planes (hi at the group's offset, lo 16 bytes behind = rs_a1)
@@ -493,7 +493,11 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
     for (int ty = 0; ty < p.kh; ++ty)
       for (int tx = 0; tx < p.kw; ++tx, ++t) {
         const int sy = r.ybase + ty * p.tsign, sx = r.xbase + tx * p.tsign;
-        if (r.ok && (unsigned)sy < (unsigned)r.SH && (unsigned)sx < (unsigned)r.SW) v |= 1u << t;
+        bool ok = r.ok && (unsigned)sy < (unsigned)r.SH && (unsigned)sx < (unsigned)r.SW;
+        // RL with the flags of the gathered tensor (sparse bwd-data): a source row outside the flagged 32-row blocks IS zero by
+        // the meaning of the flags -- it is not fetched, so a producer may leave such rows unwritten (pp_ctx_set_row_block_lazy)
+        if (RL && g_srcflags && ok) ok = g_srcflags[(r.rowbase + sy * r.SW + sx) >> 5] != 0;
+        if (ok) v |= 1u << t;
       }
     a_valid[i] = v;
   }
@@ -1354,6 +1358,7 @@ template <int TM, int TN>
 static void launch_igemm3_rowlist(hipStream_t st, IgemmParams& p, const void* ahi, const void* alo, const void* whi, const void* wlo, int w_rows,
                                   int w_ld8, void* ohi, void* olo, const unsigned char* dy_flags, unsigned char* out_flags, int* out_list,
                                   float* ws, size_t ws_bytes, bool fill = true) {
+  // (dy_flags also masks the gather: rows of the gathered tensor outside its flagged blocks are never fetched)
   constexpr int BM = 64 * TM, BN = 64 * TN;
   const int nb = (p.M + 31) / 32;
   static const int want_splits = []() { const char* e = getenv("PP_SPARSE_DGRAD_SPLITS"); return e ? atoi(e) : 2; }();
@@ -1373,15 +1378,15 @@ static void launch_igemm3_rowlist(hipStream_t st, IgemmParams& p, const void* ah
   if (ahi && !ohi)  // planes in, float32 out (a head's last conv in the forward pass)
     hipLaunchKernelGGL((igemm3f_kernel<TM, TN, true, false, false, true>), grid, dim3(256), 0, st, p, ahi, alo, (unsigned)a_bytes, whi, wlo,
                        (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)nullptr, (uint2*)nullptr, w_rows, w_ld8, splits,
-                       splits > 1 ? ws : (float*)nullptr, (const int*)out_list);
+                       splits > 1 ? ws : (float*)nullptr, (const int*)out_list, dy_flags);
   else if (ahi)  // planes in, planes out
     hipLaunchKernelGGL((igemm3f_kernel<TM, TN, true, true, false, true>), grid, dim3(256), 0, st, p, ahi, alo, (unsigned)a_bytes, whi, wlo,
                        (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)ohi, (uint2*)olo, w_rows, w_ld8, splits,
-                       splits > 1 ? ws : (float*)nullptr, (const int*)out_list);
+                       splits > 1 ? ws : (float*)nullptr, (const int*)out_list, dy_flags);
   else
     hipLaunchKernelGGL((igemm3f_kernel<TM, TN, false, false, false, true>), grid, dim3(256), 0, st, p, (const void*)p.src, nullptr,
                        (unsigned)a_bytes, whi, wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)nullptr, (uint2*)nullptr,
-                       w_rows, w_ld8, splits, splits > 1 ? ws : (float*)nullptr, (const int*)out_list);
+                       w_rows, w_ld8, splits, splits > 1 ? ws : (float*)nullptr, (const int*)out_list, dy_flags);
   if (splits > 1)
     hipLaunchKernelGGL(rl_splitk_finish_kernel, dim3((unsigned)nb), dim3(256), 0, st, p, splits, (const float*)ws, (const int*)out_list, p.bias,
                        p.addend, p.mask_src, p.out, ohi, olo);
@@ -1696,6 +1701,8 @@ extern "C" int PP_API(pp_conv2d_nhwc_bwd_data_bf16x3)(pp_ctx* ctx, const pp_conv
   const bool skip_scratch_ok = skip_flags != nullptr && skip_list_in != nullptr;
   ctx->skip_flags = nullptr;
   ctx->skip_list = nullptr;
+  const bool lazy_out = ctx->lazy_out != 0, lazy_in = ctx->lazy_in != 0;  // one-shot (pp_ctx_set_row_block_lazy)
+  ctx->lazy_out = ctx->lazy_in = 0;
   const void *ep_ah = ctx->ep_add_hi, *ep_al = ctx->ep_add_lo, *ep_mh = ctx->ep_mask_hi;  // one-shot (pp_ctx_set_epilogue_planes)
   ctx->ep_add_hi = ctx->ep_add_lo = ctx->ep_mask_hi = nullptr;
   int rc = check_desc(ctx, d, "pp_conv2d_nhwc_bwd_data_bf16x3");
@@ -1746,6 +1753,9 @@ extern "C" int PP_API(pp_conv2d_nhwc_bwd_data_bf16x3)(pp_ctx* ctx, const pp_conv
   // Contract of the hint's scratch (pp_row_block_list_planes_within relies on it): after this call the second n_blocks bytes
   // of the flags buffer flag every 32-row block of dx that may hold a non-zero -- the dilated list when the listed launch
   // runs, everything otherwise.
+  PP_CHECK_ARG(ctx, !lazy_in || rl_ok, PP_ERR_ARG,
+               "pp_conv2d_nhwc_bwd_data_bf16x3: dy was declared lazy (unwritten outside its flagged blocks) but the listed-block launch "
+               "does not apply to this call");
   if (skip_scratch_ok && !rl_ok)
     PP_HIP(ctx, hipMemsetAsync(const_cast<unsigned char*>(skip_flags) + (p.M + 31) / 32, 1, (size_t)((p.M + 31) / 32), ctx->stream));
   if (d->stride == 2 && s2_classes && (all_f32 || all_planes) && d->in.n_seg == 1) {
@@ -1799,10 +1809,10 @@ extern "C" int PP_API(pp_conv2d_nhwc_bwd_data_bf16x3)(pp_ctx* ctx, const pp_conv
     int* out_list = const_cast<int*>(skip_list_in) + nb + 1;
     if (rl_mode == 22)
       launch_igemm3_rowlist<2, 2>(ctx->stream, p, dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8, dx_hi, dx_lo, skip_flags, out_flags, out_list, ctx->ws,
-                                  ctx->ws_bytes);
+                                  ctx->ws_bytes, !lazy_out);
     else
       launch_igemm3_rowlist<1, 2>(ctx->stream, p, dy_hi, dy_lo, w_hi, w_lo, d->cin, cred / 8, dx_hi, dx_lo, skip_flags, out_flags, out_list, ctx->ws,
-                                  ctx->ws_bytes);
+                                  ctx->ws_bytes, !lazy_out);
     PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_data_bf16x3");
     return PP_OK;
   }
@@ -2363,8 +2373,8 @@ __global__ void wgrad_finish_kernel(long long n4_dw, int ld4, int splits, long l
 }
 
 template <int TM, int TN>
-static void launch_wgrad3(pp_ctx* ctx, Wgrad3Params& p, const float* x, const float* dy, const void* xhi, const void* xlo, const void* dhi,
-                          const void* dlo, float* dw, float* dbias, const int* list = nullptr) {
+static bool launch_wgrad3(pp_ctx* ctx, Wgrad3Params& p, const float* x, const float* dy, const void* xhi, const void* xlo, const void* dhi,
+                          const void* dlo, float* dw, float* dbias, const int* list = nullptr, bool lazy_in = false) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   p.k_tiles_per_tap = p.Cin / BM;
   p.n_tiles_k = p.kh * p.kw * p.k_tiles_per_tap;
@@ -2383,6 +2393,7 @@ static void launch_wgrad3(pp_ctx* ctx, Wgrad3Params& p, const float* x, const fl
   }
   p.max_wraps = (32 + min_ow - 1) / min_ow;
   const bool fast = fast_on && x_bytes < (1ll << 31) && d_bytes < (1ll << 31) && p.M < (1 << 24) && p.src_rows > 0 && min_hw >= 32;
+  if (lazy_in && !(fast && list)) return false;  // (only the listed-block reduction never looks at the other rows of dy)
   const int slots = fast ? ((TM * TN == 4) ? 3 : 4) : ((TM * TN == 4) ? 2 : 3);
   const double tile_work = (double)(TM * TN) / 4.0;
   // one slice = a full-size copy of dW plus a bias row (f32).  PP_WGRAD3_DETERMINISTIC=1 (and a scratch buffer): the splits write
@@ -2450,6 +2461,7 @@ static void launch_wgrad3(pp_ctx* ctx, Wgrad3Params& p, const float* x, const fl
   else
     hipLaunchKernelGGL((wgrad3_kernel<TM, TN, false>), dim3((unsigned)(tiles * splits)), dim3(256), 0, ctx->stream, p, x, dy,
                        (const uint4*)nullptr, (const uint4*)nullptr, (const uint4*)nullptr, (const uint4*)nullptr, dw, dbias);
+  return true;
 }
 
 }  // namespace
@@ -2459,6 +2471,8 @@ extern "C" int PP_API(pp_conv2d_nhwc_bwd_weight_bf16x3)(pp_ctx* ctx, const pp_co
   const int* skip_list = ctx->skip_list;  // one-shot (pp_ctx_set_row_block_skip)
   ctx->skip_list = nullptr;
   ctx->skip_flags = nullptr;
+  const bool lazy_in = ctx->lazy_in != 0;  // one-shot (pp_ctx_set_row_block_lazy): dy may hold anything outside the listed blocks
+  ctx->lazy_out = ctx->lazy_in = 0;
   int rc = check_desc(ctx, d, "pp_conv2d_nhwc_bwd_weight_bf16x3");
   if (rc) return rc;
   const bool planes = x_hi && x_lo && dy_hi && dy_lo;
@@ -2490,10 +2504,14 @@ extern "C" int PP_API(pp_conv2d_nhwc_bwd_weight_bf16x3)(pp_ctx* ctx, const pp_co
       big_n = e[2] == '2';
     }
   }
-  if (big_k && big_n) launch_wgrad3<2, 2>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias, skip_list);
-  else if (big_k) launch_wgrad3<2, 1>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias, skip_list);
-  else if (big_n) launch_wgrad3<1, 2>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias, skip_list);
-  else launch_wgrad3<1, 1>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias, skip_list);
+  bool launched;
+  if (big_k && big_n) launched = launch_wgrad3<2, 2>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias, skip_list, lazy_in);
+  else if (big_k) launched = launch_wgrad3<2, 1>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias, skip_list, lazy_in);
+  else if (big_n) launched = launch_wgrad3<1, 2>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias, skip_list, lazy_in);
+  else launched = launch_wgrad3<1, 1>(ctx, p, x, dy, planes ? x_hi : nullptr, x_lo, dy_hi, dy_lo, dw, dbias, skip_list, lazy_in);
+  PP_CHECK_ARG(ctx, launched, PP_ERR_ARG,
+               "pp_conv2d_nhwc_bwd_weight_bf16x3: dy was declared lazy (unwritten outside its listed blocks) but the listed-block reduction "
+               "does not apply to this call");
   PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_weight_bf16x3");
   return PP_OK;
 }

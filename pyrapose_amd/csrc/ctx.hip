@@ -72,6 +72,13 @@ extern "C" int pp_ctx_set_row_block_skip(pp_ctx* ctx, const unsigned char* flags
   return PP_OK;
 }
 
+extern "C" int pp_ctx_set_row_block_lazy(pp_ctx* ctx, int lazy_out, int lazy_in) {
+  PP_REQUIRE_CTX(ctx);
+  ctx->lazy_out = lazy_out != 0;
+  ctx->lazy_in = lazy_in != 0;
+  return PP_OK;
+}
+
 extern "C" int pp_ctx_set_row_block_out(pp_ctx* ctx, const unsigned char* flags, int* list) {
   PP_REQUIRE_CTX(ctx);
   PP_CHECK_ARG(ctx, (flags == nullptr) == (list == nullptr), PP_ERR_ARG, "pp_ctx_set_row_block_out: flags and list go together");

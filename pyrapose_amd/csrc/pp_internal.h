@@ -22,6 +22,8 @@ struct pp_ctx {
   const void* ep_mask_hi;
   const int* skip_list;              // one-shot: row-block skip of the next bf16x3 bwd-weight (list) / bwd-data (flags) call
   const unsigned char* skip_flags;
+  int lazy_out, lazy_in;             // one-shot (pp_ctx_set_row_block_lazy): the next sparse bwd-data leaves the rows of dx outside the
+                                     // blocks it computes untouched / the next bwd-data or bwd-weight's dy holds anything outside its flagged blocks
   const unsigned char* out_flags;    // one-shot: the next bf16x3 forward call computes the flagged 32-row output blocks only
   int* out_list;                     //           (pp_ctx_set_row_block_out; list = its scratch)
   int planes_fmt;                    // format of every (hi, lo) plane pair this context sees: 0 = bf16 pairs (bf16x3), 1 = P16 (f16c8)

@@ -86,11 +86,12 @@ def _view(t, pl):
 
 class Grad(object):
     """A gradient matrix: float32 (`t`) and / or bf16 planes (`pl`); rows(a, b) = the same for a row range."""
-    __slots__ = ("t", "pl", "within", "fmt")
+    __slots__ = ("t", "pl", "within", "fmt", "lazy")
 
     def __init__(self, t, pl=None, fmt=0):
         self.t, self.pl, self.fmt = t, pl, int(fmt)  # fmt: plane format of `pl` (a P16 gradient also carries the factor 2^G)
         self.within = None  # uint8 flags of the only 32-row blocks that can hold a non-zero (a sparse data gradient without addend)
+        self.lazy = False   # the rows outside `within` were never written (pp_ctx_set_row_block_lazy): every reader goes by flags
 
     def rows(self, r0, r1):
         return Grad(None if self.t is None else self.t[r0:r1], None if self.pl is None else (self.pl[0][r0:r1], self.pl[1][r0:r1]), self.fmt)
@@ -796,9 +797,10 @@ class Engine(object):
             return Grad(None, _new_planes(rows, ld), fmt)
         return Grad(torch.empty((rows, ld), dtype=torch.float32, device="cuda"))
 
-    def _finalize(self, act):
+    def _finalize(self, act, producer=None):
         """Sum the gradient contributions of `act`; the ReLU mask (act > 0) is folded into the last
-        data-gradient launch.  Returns the gradient w.r.t. the pre-activation (a Grad), or None."""
+        data-gradient launch.  Returns the gradient w.r.t. the pre-activation (a Grad), or None.
+        producer: the op whose backward will read that gradient (decides whether a sparse launch may leave it unfilled)."""
         ctx = self.ctx.twin(act.fmt)  # (every contribution to a tensor is in that tensor's plane format: its consumers read it so)
         grads = [c[1] for c in act.contribs if c[0] in ("tensor", "masked")]  # masked: the ReLU of `act` is already applied
         dgrads = [c for c in act.contribs if c[0] == "dgrad"]
@@ -836,6 +838,13 @@ class Engine(object):
                 in_place = (sk is not None and i > 0 and mask is None and acc is not None and gcap is None
                             and _os.environ.get("PP_SPARSE_INPLACE", "1") != "0")
                 out = acc if in_place else self._new_grad(act.rows, act.ld, act.fmt)
+                # Lazy: the only readers of this gradient are the backward launches of a sparse layer (its scan restricted to the
+                # blocks this launch computes, its listed-block weight gradient, its listed-block data gradient) -- the rows outside
+                # those blocks are never looked at, so the 103 MB fill pass of zeros is not made (3D-box head: four per step)
+                lazy_out = (sk is not None and len(dgrads) == 1 and acc is None and gcap is None and gy.pl is not None and out.pl is not None
+                            and self._lazy_reader(producer) and _os.environ.get("PP_SPARSE_WITHIN", "1") != "0"
+                            and _os.environ.get("PP_SPARSE_LAZY", "1") != "0" and _os.environ.get("PP_SPARSE_DGRAD", "22") != "0")
+                lazy_in = bool(gy.lazy)
                 # every operand in the format it exists in (planes where there is no float32 copy)
                 dy_t, dy_pl = (None, gy.pl) if gy.pl is not None else (gy.t, None)
                 a_t = a_pl = m_t = m_hi = None
@@ -846,11 +855,15 @@ class Engine(object):
                 if gcap is not None:
                     assert dy_t is not None
                 self.bwd_ops.append(Op(lambda d=op["desc"], dy_t=dy_t, dy_pl=dy_pl, dh=pl["dg_hi"], dl=pl["dg_lo"], a_t=a_t, a_pl=a_pl, m_t=m_t,
-                                       m_hi=m_hi, out=out, gcap=gcap, sk=sk:
-                                       ops.conv_bwd_data3(ctx, d, dy_t, dh, dl, a_t, m_t, out.t, dy_pl, out.pl, gcap, sk, a_pl, m_hi), "conv_dgrad",
+                                       m_hi=m_hi, out=out, gcap=gcap, sk=sk, lazy_out=lazy_out, lazy_in=lazy_in:
+                                       ops.conv_bwd_data3(ctx, d, dy_t, dh, dl, a_t, m_t, out.t, dy_pl, out.pl, gcap, sk, a_pl, m_hi,
+                                                          lazy_out=lazy_out, lazy_in=lazy_in), "conv_dgrad",
                                        op["spec"].name, op["flops"]))
-                # a row-block-skip launch without addend leaves zeros outside the blocks it flags in the second half of its scratch
+                # a row-block-skip launch without addend leaves zeros (lazy: nothing at all) outside the blocks it flags in the second
+                # half of its scratch
                 out.within = sk[0][sk[0].numel() // 2:] if (sk is not None and acc is None and _os.environ.get("PP_SPARSE_WITHIN", "1") != "0") else None
+                out.lazy = lazy_out
+                assert not lazy_out or out.within is not None
                 pw = op.pop("pending_wgrad", None)
                 if pw is not None:  # the layer's weight gradient reads the planes this launch has just written
                     self.bwd_ops.append(pw)
@@ -862,6 +875,18 @@ class Engine(object):
                                        ops.conv_bwd_data(ctx, d, gy.t, w, a, m, out.t), "conv_dgrad", op["spec"].name, op["flops"]))
             acc = out
         return acc
+
+    def _lazy_reader(self, producer):
+        """is `producer` (the op that made the activation whose gradient is being formed) a layer whose whole backward goes by
+        row-block flags?  a sparse 3x3 stride-1 conv without residual, planes on both sides, not the first layer of the graph"""
+        if producer is None or producer.get("kind") != "conv" or producer.get("residual") is not None:
+            return False
+        s_, pl_, x_, y_ = producer["spec"], producer.get("planes"), producer["x"], producer["y"]
+        # (the listed-block launches are forms of the buffer-addressed loops: their conditions, csrc/conv3.hip igemm3_fast_ok /
+        # launch_wgrad3 -- the C side refuses a lazy operand where they do not hold, this keeps the plan away from that)
+        geo = (_os.environ.get("PP_CONV3_FAST", "1") != "0" and min(h * w for h, w in x_.shapes) >= 32 and x_.rows < (1 << 24)
+               and x_.rows * x_.ld * 4 < (1 << 31) and y_.rows * y_.ld * 4 < (1 << 31) and list(x_.shapes) == list(y_.shapes))
+        return self._sparse_layer(s_) and pl_ is not None and pl_["dg_hi"] is not None and x_.pl is not None and y_.pl is not None and geo
 
     def _build_backward(self):
         ctx, P = self.ctx, self.params
@@ -886,7 +911,7 @@ class Engine(object):
             y = op["y"]
             if not y.needs_grad:
                 continue
-            g = self._finalize(y)
+            g = self._finalize(y, op)
             if g is None:
                 continue
             if kind == "convert":
@@ -940,9 +965,10 @@ class Engine(object):
                         both = x.pl is not None and g.pl is not None
                         assert both or (x.t is not None and g.t is not None), "weight gradient of %s: operands in different formats" % s.name
                         sk = op.get("skip")
+                        assert not g.lazy or (both and sk is not None), s.name
                         fn = lambda d=op["desc"], xt=(None if both else x.t), gt=(None if both else g.t), dw=dw, db=db, wctx=wctx, \
-                            xp=(x.pl if both else None), gp=(g.pl if both else None), sk=sk: \
-                            ops.conv_bwd_weight3(wctx, d, xt, gt, dw, db, xp, gp, sk)
+                            xp=(x.pl if both else None), gp=(g.pl if both else None), sk=sk, lz=g.lazy: \
+                            ops.conv_bwd_weight3(wctx, d, xt, gt, dw, db, xp, gp, sk, lazy_in=lz)
                     else:
                         assert x.t is not None and g.t is not None, s.name
                         fn = lambda d=op["desc"], xt=x.t, g=g, dw=dw, db=db, wctx=wctx: ops.conv_bwd_weight(wctx, d, xt, g.t, dw, db)

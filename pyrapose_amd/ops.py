@@ -334,9 +334,13 @@ def set_row_block_out(ctx, flags, blocks):
     check(lib.pp_ctx_set_row_block_out(ctx.handle, _ptr(flags), _ptr(blocks)), ctx.handle, "pp_ctx_set_row_block_out")
 
 
-def _set_skip(ctx, skip):
+def _set_skip(ctx, skip, lazy_out=False, lazy_in=False):
     if skip is not None:
         check(lib.pp_ctx_set_row_block_skip(ctx.handle, _ptr(skip[0]), _ptr(skip[1])), ctx.handle, "pp_ctx_set_row_block_skip")
+    if lazy_out or lazy_in:
+        if skip is None:
+            raise ValueError("lazy sparse gradients go with a row-block skip hint (dy_skip)")
+        check(lib.pp_ctx_set_row_block_lazy(ctx.handle, int(bool(lazy_out)), int(bool(lazy_in))), ctx.handle, "pp_ctx_set_row_block_lazy")
 
 
 def conv_fwd3(ctx, d, x, w_hi, w_lo, bias, residual, relu, y, x_planes=None, y_planes=None, x_capture=None, res_planes=None):
@@ -353,12 +357,13 @@ def conv_fwd3(ctx, d, x, w_hi, w_lo, bias, residual, relu, y, x_planes=None, y_p
 
 
 def conv_bwd_data3(ctx, d, dy, w_hi, w_lo, addend, relu_src, dx, dy_planes=None, dx_planes=None, dy_capture=None, dy_skip=None,
-                   addend_planes=None, relu_src_hi=None):
+                   addend_planes=None, relu_src_hi=None, lazy_out=False, lazy_in=False):
     """dy_capture = (hi, lo): the launch also writes the bf16 split of dy (pp_ctx_set_split_capture).
     dy_skip = (flags, list) from row_block_list(dy): tiles that only see zero blocks of dy skip their reduction.
-    addend_planes = (hi, lo) / relu_src_hi = hi plane: those epilogue operands as planes (pp_ctx_set_epilogue_planes)."""
+    addend_planes = (hi, lo) / relu_src_hi = hi plane: those epilogue operands as planes (pp_ctx_set_epilogue_planes).
+    lazy_out / lazy_in: pp_ctx_set_row_block_lazy (dx is left unwritten outside the computed blocks / dy is such a tensor)."""
     _set_capture(ctx, dy_capture)
-    _set_skip(ctx, dy_skip)
+    _set_skip(ctx, dy_skip, lazy_out, lazy_in)
     _set_epilogue_planes(ctx, addend_planes, relu_src_hi)
     ld_add = addend.stride(0) if addend is not None else (planes_ld(addend_planes) if addend_planes is not None else 0)
     ld_rs = relu_src.stride(0) if relu_src is not None else (relu_src_hi.stride(0) // 2 if relu_src_hi is not None else 0)
@@ -369,9 +374,10 @@ def conv_bwd_data3(ctx, d, dy, w_hi, w_lo, addend, relu_src, dx, dy_planes=None,
           "pp_conv2d_nhwc_bwd_data_bf16x3")
 
 
-def conv_bwd_weight3(ctx, d, x, dy, dw, dbias, x_planes=None, dy_planes=None, dy_skip=None):
-    """dy_skip = (flags, list) from row_block_list(dy): the reduction walks the listed 32-row blocks only."""
-    _set_skip(ctx, dy_skip)
+def conv_bwd_weight3(ctx, d, x, dy, dw, dbias, x_planes=None, dy_planes=None, dy_skip=None, lazy_in=False):
+    """dy_skip = (flags, list) from row_block_list(dy): the reduction walks the listed 32-row blocks only.
+    lazy_in: dy is unwritten outside those blocks (pp_ctx_set_row_block_lazy): fails unless the listed-block reduction runs."""
+    _set_skip(ctx, dy_skip, False, lazy_in)
     xh, xl = x_planes if x_planes is not None else (None, None)
     dh, dl = dy_planes if dy_planes is not None else (None, None)
     check(lib.pp_conv2d_nhwc_bwd_weight_bf16x3(ctx.handle, C.byref(d), _ptr(x), _ptr(dy), _ptr(xh), _ptr(xl), _ptr(dh), _ptr(dl),

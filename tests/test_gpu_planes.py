@@ -418,3 +418,65 @@ def test_weight_gradient_slices_are_deterministic_and_match_atomics(ctx, case, m
     assert float((s_db - a_db).abs().max()) <= 4e-5 * max(float((a_db - 1).abs().max()), 1e-30)
     assert bool(s_dw.isfinite().all()) and float((s_dw - base).abs().max()) > 0
     assert torch.equal(s_dw[:, cout:], base[:, cout:])   # padding columns: + 0
+
+
+def test_lazy_sparse_gradients(ctx):
+    """pp_ctx_set_row_block_lazy: a listed-block data gradient that leaves the rows outside its blocks UNWRITTEN, and consumers that
+    never look at them -- the restricted scan, the listed-block data gradient (its gather skips rows outside the flagged blocks of
+    dy) and the listed-block weight gradient give what they give on the zero-filled tensor; a launch that would read the unwritten
+    rows refuses the call."""
+    from pyrapose_amd import ops
+    rng = np.random.default_rng(23)
+    B, shapes, c1, c2, k = 2, [(20, 26), (10, 13), (6, 7)], 128, 64, 3
+    rows = sum(B * h * w for h, w in shapes)
+    nb = (rows + 31) // 32
+    i16 = dict(dtype=torch.int16, device="cuda")
+    d_b = ops.make_conv_desc(B, shapes, shapes, c1, c2, k, 1, 1, 1, c1, c2, c2)  # layer b: c1 -> c2 (its dy is sparse, its dx lazy)
+    d_a = ops.make_conv_desc(B, shapes, shapes, c1, c1, k, 1, 1, 1, c1, c1, c1)  # layer a in front of it: c1 -> c1 (reads the lazy tensor)
+    wb = torch.as_tensor(rng.standard_normal((k * k * c1, c2)) * 0.05, dtype=torch.float32).cuda()
+    wa = torch.as_tensor(rng.standard_normal((k * k * c1, c1)) * 0.05, dtype=torch.float32).cuda()
+    bh, bl = torch.zeros((k * k, c1, c2), **i16), torch.zeros((k * k, c1, c2), **i16)
+    ah, al = torch.zeros((k * k, c1, c1), **i16), torch.zeros((k * k, c1, c1), **i16)
+    ops.conv_split_weights3(ctx, d_b, wb, torch.zeros((k * k, c2, c1), **i16), torch.zeros((k * k, c2, c1), **i16), bh, bl)
+    ops.conv_split_weights3(ctx, d_a, wa, torch.zeros((k * k, c1, c1), **i16), torch.zeros((k * k, c1, c1), **i16), ah, al)
+    dy = torch.zeros((rows, c2), dtype=torch.float32, device="cuda")
+    live = torch.as_tensor(rng.uniform(size=rows) < 0.01).cuda()
+    dy[live] = torch.as_tensor(rng.standard_normal((int(live.sum()), c2)), dtype=torch.float32).cuda()
+    gp = split(ctx, dy)
+    msk = split(ctx, torch.relu(torch.as_tensor(rng.standard_normal((rows, c1)), dtype=torch.float32)).cuda())
+    xa = split(ctx, torch.as_tensor(rng.standard_normal((rows, c1)), dtype=torch.float32).cuda())
+    res = {}
+    for lazy in (False, True):
+        f, b = ops.row_block_list(ctx, dy, c2)
+        g1 = nan_planes(torch.empty((rows, c1)))
+        ops.conv_bwd_data3(ctx, d_b, None, bh, bl, None, None, None, dy_planes=gp, dx_planes=g1, dy_skip=(f, b), relu_src_hi=msk[0], lazy_out=lazy)
+        within = f[nb: 2 * nb].clone()
+        assert 0 < int(within.sum()) < nb
+        f1, b1 = torch.zeros_like(f), torch.zeros_like(b)
+        ops.row_block_list_planes(ctx, g1, c1, f1, b1, within=within)
+        g0 = nan_planes(torch.empty((rows, c1)))
+        ops.conv_bwd_data3(ctx, d_a, None, ah, al, None, None, None, dy_planes=g1, dx_planes=g0, dy_skip=(f1, b1), lazy_in=lazy)
+        dw, db = torch.zeros_like(wa), torch.zeros((c1,), device="cuda")
+        ops.conv_bwd_weight3(ctx, d_a, None, None, dw, db, x_planes=xa, dy_planes=g1, dy_skip=(f1, b1), lazy_in=lazy)
+        torch.cuda.synchronize()
+        res[lazy] = (raw(g1), within, f1[:nb].clone(), b1[: nb + 1].clone(), raw(g0), dw, db)
+    (z1, wz, fz, bz, z0, dwz, dbz), (l1, wl, fl_, bl_, l0, dwl, dbl) = res[False], res[True]
+    assert torch.equal(wz, wl) and torch.equal(fz, fl_) and torch.equal(bz, bl_)
+    rows_in = wz.bool().repeat_interleave(32)[:rows]
+    for a, b_ in zip(z1, l1):  # the computed blocks are the same bits; the others: zeros when filled, the NaN pattern when lazy
+        assert torch.equal(a[rows_in], b_[rows_in])
+        assert not a[~rows_in].any()
+    assert bool((l1[0][~rows_in] == 0x7fc0).all())
+    for a, b_ in zip(z0, l0):  # the next layer's data gradient never fetched an unwritten row
+        assert torch.equal(a, b_)
+    assert float((dwz - dwl).abs().max()) <= 2e-6 * float(dwz.abs().max()) and not torch.isnan(dwl).any()
+    assert float((dbz - dbl).abs().max()) <= 1e-5 * max(float(dbz.abs().max()), 1e-30)
+    # refusals: a 1x1 data gradient and a weight gradient without a block list cannot honour a lazy dy
+    d1 = ops.make_conv_desc(B, shapes, shapes, c1, c1, 1, 1, 0, 0, c1, c1, c1)
+    w1h, w1l = torch.zeros((1, c1, c1), **i16), torch.zeros((1, c1, c1), **i16)
+    f1, b1 = ops.row_block_list(ctx, dy, c2)
+    with pytest.raises(ValueError):
+        ops.conv_bwd_data3(ctx, d1, None, w1h, w1l, None, None, None, dy_planes=xa, dx_planes=nan_planes(torch.empty((rows, c1))), dy_skip=(f1, b1),
+                           lazy_in=True)
+    with pytest.raises(ValueError):
+        ops.conv_bwd_weight3(ctx, d_a, None, None, torch.zeros_like(wa), None, x_planes=xa, dy_planes=xa, lazy_in=True)
