@@ -3,7 +3,7 @@
 
 #include "pp_internal.h"
 
-extern "C" const char* pp_version(void) { return "pyrapose_hip 0.5 (gfx950; f16c8 (f16 + block-scaled e5m2 MFMA) + f32 MFMA convolutions on packed P16 planes, sparse 3D-box backward, pose tail, device augmentation)"; }
+extern "C" const char* pp_version(void) { return "pyrapose_hip 0.6 (gfx950; convolutions on packed planes in two formats -- bf16 pairs / bf16x3 and P16 / f16c8 (f16 + block-scaled e5m2 MFMA) -- and exact f32 MFMA; sparse 3D-box backward, pose tail, device augmentation)"; }
 
 extern "C" int pp_ctx_create(pp_ctx** out, int device, void* hip_stream) {
   if (!out) return PP_ERR_ARG;
