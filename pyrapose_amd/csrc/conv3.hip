@@ -103,7 +103,7 @@ __device__ __forceinline__ int div_small(int a, int b, float rcp_b, int* rem) {
 // (Measured and not kept: non-temporal stores for the output tile -- the next launch reads it back, and the step lost 1 %.)
 // RL: the tile's BM rows are BM / 32 listed 32-row blocks (rl_blk[j] = first row of block j of this tile, >= M when the
 // list has ended) instead of the consecutive rows m0 ..
-template <int TM, int TN, bool OP, int GOP = 1, bool SC = false, bool XR = false, bool RL = false>
+template <int TM, int TN, bool OP, int GOP = 1, bool SC = false, bool XR = false, bool RL = false, int NWM = 2, int NT = 256>
 __device__ __forceinline__ void epilogue3(const IgemmParams& p, floatx16 (&acc)[TM][TN], uint4* smem, int m0, int n0, int tid, int wm,
                                           int wn, int il, int h, const float* __restrict__ g_bias,
                                           const float* __restrict__ g_addend, const float* __restrict__ g_mask,
@@ -115,9 +115,10 @@ __device__ __forceinline__ void epilogue3(const IgemmParams& p, floatx16 (&acc)[
   constexpr int SUB = (TM == 4) ? 2 : ((TM * BN > 256 * 1) ? 1 : TM);  // 32*SUB rows x BN floats must fit the LDS buffer
   constexpr int ROWS = 32 * SUB;
   constexpr int C4 = BN / 4;
-  constexpr int RPI = 256 / C4;
+  constexpr int RPI = NT / C4;
   constexpr int SWEEPS = ROWS / RPI;
   static_assert(ROWS * BN * 4 <= SMEM_U4 * 16, "epilogue staging does not fit");
+  static_assert(SWEEPS >= 1 && ROWS % RPI == 0, "epilogue sweep geometry");
   float* stage = reinterpret_cast<float*>(smem);
   const int e_c4 = tid % C4, e_r = tid / C4;
   const int co = n0 + 4 * e_c4;
@@ -128,7 +129,7 @@ __device__ __forceinline__ void epilogue3(const IgemmParams& p, floatx16 (&acc)[
   const int m_last = p.M - 1;
   const bool add_pl = p.add_hi != nullptr, mask_pl = p.mask_hi != nullptr;  // (uniform) operands stored as bf16 planes
 #pragma unroll
-  for (int hm = 0; hm < 2; ++hm) {
+  for (int hm = 0; hm < NWM; ++hm) {
 #pragma unroll
     for (int a0 = 0; a0 < TM; a0 += SUB) {
       __syncthreads();
@@ -224,7 +225,7 @@ __device__ __forceinline__ void epilogue3(const IgemmParams& p, floatx16 (&acc)[
               if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
               // XR (igemm3x): tile rows 0 and BM - 1 are halo rows that the neighbouring tiles own
               const int trow = hm * 32 * TM + a0 * 32 + row;
-              if (m <= m_last && (!XR || (trow >= 1 && trow <= 64 * TM - 2))) {
+              if (m <= m_last && (!XR || (trow >= 1 && trow <= 32 * TM * NWM - 2))) {
                 if (!OP || g_out != nullptr) *reinterpret_cast<float4*>(g_out + (long long)mo[g] * p.ld_out + co) = v;
               }
               if (OP) {
@@ -236,7 +237,7 @@ __device__ __forceinline__ void epilogue3(const IgemmParams& p, floatx16 (&acc)[
                 const unsigned sx = odd ? oh.x : ol.x, sy = odd ? oh.y : ol.y;
                 const unsigned rx = lane_xor1(sx), ry = lane_xor1(sy);
                 const uint4 o16 = odd ? make_uint4(rx, ry, ol.x, ol.y) : make_uint4(oh.x, oh.y, rx, ry);
-                if (m <= m_last && (!XR || (trow >= 1 && trow <= 64 * TM - 2))) {
+                if (m <= m_last && (!XR || (trow >= 1 && trow <= 32 * TM * NWM - 2))) {
                   const long long grp = ((long long)mo[g] * p.ld_out + (co & ~7)) >> 3;  // 32-byte group
                   reinterpret_cast<uint4*>(g_ohi)[2 * grp + (odd ? 1 : 0)] = o16;
                 }
@@ -910,6 +911,178 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
   epilogue3<TM, TN, OP, 4, false, true>(p, acc, smem, m0, n0, tid, wm, wn, il, h, g_bias, g_addend, g_mask, g_out, g_ohi, g_olo);
 }
 
+// ---- igemm4x (EXPERIMENTAL, PP_CONV3_DMA=1): igemm3x's arithmetic and tap-row reuse on a multi-stage LDS-DMA pipeline ----
+// One workgroup of 8 waves per CU, tile 256 x 128 (wave tile 64 x 64 as before).  Both operands reach LDS by buffer_load ... lds
+// (no staging registers): a wave-instruction writes 64 lane-consecutive 16-byte slots, so the rotated LDS image is produced on the
+// SOURCE side -- the lane at LDS slot s fetches the piece that belongs at s (wave w: k-octet w & 3; gathered operand: rows half
+// w >> 2, two chunks of 64 slots; weights: chunk w >> 2).  Rings: 2 stages of the gathered tile (one per (ty, chunk) group: loaded
+// three taps ahead), 4 stages of the weight tile (three taps ahead); one barrier per tap, counted vmcnt waits (never 0 in the
+// loop): issue order per tap start = [gathered tile of the next group, at tx == 0] then the weight tile of tap t + 3.
+// Planes in, planes out, splits == 1, kh == 3, kernel row innermost (x_ty_inner), w_rows % 128 == 0.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, uint4* lds, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+template <bool OP>
+__global__ __launch_bounds__(512, 1) void igemm4x_kernel(
+    const IgemmParams p, const void* __restrict__ g_a, const void* __restrict__ g_a1, unsigned a_bytes, const void* __restrict__ g_whi,
+    const void* __restrict__ g_wlo, unsigned w_bytes, const float* __restrict__ g_bias, const float* __restrict__ g_addend,
+    const float* __restrict__ g_mask, float* __restrict__ g_out, uint2* __restrict__ g_ohi, uint2* __restrict__ g_olo, int w_rows, int w_ld8) {
+  constexpr int TM = 2, TN = 2, NWM = 4, BM = 32 * TM * NWM, BN = 128, BK = 32, NO = BK / 8, ES = 4;
+  constexpr int AP1 = NO * BM + 1, A_STAGE = 2 * AP1, B_STAGE = 2 * NO * BN;
+  // every stage is an LDS object of its own: the compiler's LDS-DMA tracking (alias scopes per object) then inserts COUNTED vmcnt
+  // waits in front of a fragment read -- for the DMA into that stage only -- instead of draining everything in flight
+  __shared__ __attribute__((aligned(16))) uint4 sA0[A_STAGE];
+  __shared__ __attribute__((aligned(16))) uint4 sA1[A_STAGE];
+  __shared__ __attribute__((aligned(16))) uint4 sB0[B_STAGE];
+  __shared__ __attribute__((aligned(16))) uint4 sB1[B_STAGE];
+  __shared__ __attribute__((aligned(16))) uint4 sB2[B_STAGE];
+  auto stA = [&](auto k) -> uint4* {
+    if constexpr (decltype(k)::value == 0) return sA0; else return sA1;
+  };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lb = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int tile_n = lb % p.n_tiles_n, tile_m = lb / p.n_tiles_n;
+  const int m0 = tile_m * (BM - 2) - 1, n0 = tile_n * BN;
+  const int il = lane & 31, h = lane >> 5;
+  const int n_chunks = p.Cred / BK;
+  const int G = p.kh * n_chunks;  // groups: (chunk, ty), ty innermost
+
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_a), 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_a1), 0, a_bytes - 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_whi), 0, w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_wlo), 0, w_bytes, 0x00020000);
+
+  // DMA lanes: octet plane o; gathered tile: slots 128 * hp + 64 * c + lane of that plane (c = 0, 1) <-> tile row (slot - 2 o) & 255
+  const int o = wave & 3, hp = wave >> 2;
+  int s_base[2], s_pitch[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int j = (128 * hp + 64 * c + lane - 2 * o) & (BM - 1);
+    const int q = m0 + j;
+    const RowPos r = decode_row(p, q < 0 ? 0 : q);
+    const bool ok = q >= 0 && r.ok;
+    const int x = r.xbase - p.off_x;
+    s_base[c] = ((r.rowbase + r.ybase * r.SW + x) * p.ld_src + 8 * o) * ES;
+    int v = 0;
+    for (int ty = 0; ty < 3; ++ty)
+      if (ok && (unsigned)(r.ybase + ty * p.tsign) < (unsigned)r.SH) v |= 1 << ty;
+    s_pitch[c] = (p.tsign * r.SW * p.ld_src * ES) | v;
+  }
+  // weight tile: slot 64 * hp + lane of plane o <-> weight row (slot - 2 o) & 127
+  const int b_n = n0 + ((64 * hp + lane - 2 * o) & (BN - 1));
+  const int b_dma = b_n < w_rows ? (b_n * w_ld8 + o) * 16 : PP_BUF_OOB;
+  const int b_tap = w_rows * w_ld8 * 16;
+
+  unsigned f_valid = 0;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const int q = m0 + wm * 32 * TM + a * 32 + il;
+    const RowPos r = decode_row(p, q < 0 ? 0 : q);
+    unsigned v = 0;
+    int t = 0;
+    for (int ty = 0; ty < 3; ++ty)
+      for (int tx = 0; tx < 3; ++tx, ++t) {
+        const int sy = r.ybase + ty * p.tsign, sx = r.xbase + tx * p.tsign;
+        if (q >= 0 && r.ok && (unsigned)sy < (unsigned)r.SH && (unsigned)sx < (unsigned)r.SW) v |= 1u << t;
+      }
+    f_valid |= v << (16 * (a & 1));
+  }
+
+  auto dma_a = [&](int g, uint4* st) {  // the gathered tile of group g -> stage st
+    const int ty = g % 3, chunk = g / 3;
+    uint4* const hi = st + o * BM + 128 * hp;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      int vo = s_base[c] + __mul24(ty, s_pitch[c] & ~15) + chunk * (BK * ES);
+      vo = ((s_pitch[c] >> ty) & 1) ? vo : PP_BUF_OOB;
+      dma16(rs_a, hi + 64 * c, vo, 0);
+      dma16(rs_a1, hi + AP1 + 64 * c, vo, 0);
+    }
+  };
+  auto dma_b = [&](int g, int tx, uint4* st) {  // the weight tile of tap (group g, tx) -> stage st
+    const int ty = g % 3, chunk = g / 3;
+    const int b_uni = ((p.w_ty0 + ty) * p.w_kw + tx) * b_tap + chunk * (BK / 8 * 16);
+    uint4* const hi = st + o * BN + 64 * hp;
+    dma16(rs_wh, hi, b_dma, b_uni);
+    dma16(rs_wl, hi + NO * BN, b_dma, b_uni);
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  auto mma_tile = [&](int c_ty, int TX, const uint4* Ahi, const uint4* Bhi) {
+    const int dx = p.off_x + TX * p.tsign;
+    const unsigned tap_bits = (1u << (c_ty * 3 + TX)) * 0x10001u;
+    const unsigned okm = f_valid & tap_bits;
+    unsigned a_ok = 0;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) a_ok |= (((okm >> (16 * (a & 1))) & 0xffffu) != 0 ? 1u : 0u) << a;
+    mma_step<TM, TN, BM, BN, 1>(acc, Ahi, Ahi + AP1, Bhi, Bhi + NO * BN, wm * 32 * TM + il + dx, wn * 32 * TN + il, h, a_ok, NO * BM);
+  };
+  std::integral_constant<int, 0> c0;
+  std::integral_constant<int, 1> c1;
+  std::integral_constant<int, 2> c2;
+  std::integral_constant<int, 4> c4;
+  std::integral_constant<int, 6> c6;
+  // Weight ring of THREE stages: the stage of a tap is its tx (compile time without unrolling over groups), the tile of tap t + 2
+  // goes into the stage tap t - 1 has just left; gathered ring of two stages (unrolled over two groups), loaded one group ahead.
+  // Issue order at a tap's start: [gathered tile of the next group, at tx == 0], weight tile of tap t + 2.  At the end of tap t the
+  // tile of tap t + 1 (issued at tap t - 1) must have landed: instructions issued after it = tx 0: 4 (A) + 2 = 6; tx 1: 2;
+  // tx 2: 2 -- and the gathered tile of group g + 1 (issued at tx 0, before the weight tile waited for at tx 1) is then in.
+  auto group = [&](int g, auto k) {
+    constexpr int K = decltype(k)::value;
+    const int c_ty = g % 3;
+    const int gn = g + 1 < G ? g + 1 : 0;  // past the end: group 0 again (a harmless re-load)
+    uint4* const Ahi = stA(std::integral_constant<int, K & 1>{});
+    dma_a(gn, stA(std::integral_constant<int, (K + 1) & 1>{}));
+    dma_b(g, 2, sB2);
+    mma_tile(c_ty, 0, Ahi, sB0);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    dma_b(gn, 0, sB0);
+    mma_tile(c_ty, 1, Ahi, sB1);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    dma_b(gn, 1, sB1);
+    mma_tile(c_ty, 2, Ahi, sB2);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  if (tid == 0) {
+    sA0[NO * BM] = make_uint4(0u, 0u, 0u, 0u);
+    sA0[AP1 + NO * BM] = make_uint4(0u, 0u, 0u, 0u);
+    sA1[NO * BM] = make_uint4(0u, 0u, 0u, 0u);
+    sA1[AP1 + NO * BM] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  // prologue: group 0 and the weight tiles of taps 0, 1
+  dma_a(0, sA0);
+  dma_b(0, 0, sB0);
+  dma_b(0, 1, sB1);
+  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  for (int g = 0; g < G; g += 2) {
+    group(g, c0);
+    if (g + 1 >= G) break;
+    group(g + 1, c1);
+  }
+  (void)c2; (void)c4; (void)c6;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the look-ahead loads of a group that never comes: landed before LDS is reused
+  __syncthreads();
+  epilogue3<TM, TN, OP, 4, false, true, false, NWM, 512>(p, acc, sA0, m0, n0, tid, wm, wn, il, h, g_bias, g_addend, g_mask, g_out, g_ohi, g_olo);
+}
+
 // epilogue arithmetic of the pointwise finishing kernels: v (+ addend) (masked by the ReLU source) (ReLU) -> f32 and / or planes;
 // mo = row of the addend / mask / output tensors, co = first of four columns
 __device__ __forceinline__ void finish4(const IgemmParams& p, float4 v, long long mo, int co, bool with_addend, const float* __restrict__ g_addend,
@@ -1446,6 +1619,20 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
           hipLaunchKernelGGL((igemm3x_kernel<TM, TN, true>), gridx, dim3(256), 0, st, p, (const void*)p.src, nullptr, (unsigned)a_bytes, whi, wlo,
                              (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)nullptr, (uint2*)nullptr, w_rows, w_ld8, splits,
                              ws, chi, clo, flags, skip_halo);
+          return;
+        }
+      }
+      if constexpr (TM == 2 && TN == 2) {
+        // EXPERIMENTAL (PP_CONV3_DMA=1): the multi-stage LDS-DMA form of this launch (igemm4x_kernel), planes in and out
+        static const bool dma_on = []() { const char* e = getenv("PP_CONV3_DMA"); return e && e[0] == '1'; }();
+        if (dma_on && ahi && op && !flags && splits == 1 && p.kh == 3 && x_order == 1 && w_rows % 128 == 0 && p.Cred % 32 == 0) {
+          constexpr int BM4 = 256;
+          constexpr size_t smem_bytes = 0;  // (static LDS: one object per stage)
+          const int n_tiles_m4 = (p.M + BM4 - 3) / (BM4 - 2);
+          p.n_tiles_n = (p.Nout + 127) / 128;
+          hipLaunchKernelGGL((igemm4x_kernel<true>), dim3((unsigned)(n_tiles_m4 * p.n_tiles_n)), dim3(512), smem_bytes, st, p, ahi, alo,
+                             (unsigned)a_bytes, whi, wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)ohi, (uint2*)olo, w_rows,
+                             w_ld8);
           return;
         }
       }

@@ -172,6 +172,18 @@ def main():
                 err = got - ref
                 print("        centre tap vs float64: rel-L2 %.3e  max|err|/max|ref| %.3e" %
                       (float(err.norm() / ref.norm()), float(err.abs().max() / ref.abs().max())), flush=True)
+            if args.check and mode == "fwd3pp":
+                # planes out: decode and compare every row of level 0 (all images) against float64; also a checksum of the raw planes
+                import torch.nn.functional as F
+                h0, w0 = shapes[0]
+                got = ops.planes_to_f32((yh, yl), args.fmt)[: B * h0 * w0, :cout].double()
+                xi = ops.planes_to_f32((xh, xl), args.fmt)[: B * h0 * w0].double().reshape(B, h0, w0, cin).permute(0, 3, 1, 2)
+                wt = w[:, :cout].double().reshape(k, k, cin, cout).permute(3, 2, 0, 1)
+                ref = F.relu(F.conv2d(xi, wt, None, stride=stride, padding=pad)).permute(0, 2, 3, 1).reshape(-1, cout)
+                err = got - ref
+                print("        planes out vs float64 (level 0, all images): rel-L2 %.3e  max|err|/max|ref| %.3e  checksum %d" %
+                      (float(err.norm() / ref.norm()), float(err.abs().max() / ref.abs().max()),
+                       int(yh.to(torch.int64).sum() * 3 + yl.to(torch.int64).sum())), flush=True)
             if args.check and mode in ("fwd", "fwd3", "fwd3p", "fwd2"):
                 # error of the launch against float64 (torch on the device, a sample of the output rows of the first level)
                 import torch.nn.functional as F
