@@ -954,25 +954,28 @@ __global__ __launch_bounds__(512, 1) void igemm4x_kernel(
   const __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_whi), 0, w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_wlo), 0, w_bytes, 0x00020000);
 
-  // DMA lanes: octet plane o; gathered tile: slots 128 * hp + 64 * c + lane of that plane (c = 0, 1) <-> tile row (slot - 2 o) & 255
-  const int o = wave & 3, hp = wave >> 2;
-  int s_base[2], s_pitch[2];
+  // DMA lanes (LDS images of planes_fmt.h LAY 1, filled in FULL lines).  Gathered tile: one instruction = 8 rows x 8 pieces (the
+  // 128 contiguous bytes [hi0 lo0 .. hi3 lo3] of a row's 32-channel chunk); wave w owns rows 32 w .. 32 w + 31 in four instructions;
+  // the lane at LDS piece position q of row r fetches piece q ^ ((r / 2) mod 8).  Weight tile, per plane: one instruction = 16
+  // rows x 4 pieces (64 contiguous bytes); wave w owns rows 16 w .. 16 w + 15; piece q of row n is octet q ^ ((n / 4) mod 4).
+  int s_base[4], s_pitch[4];
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const int j = (128 * hp + 64 * c + lane - 2 * o) & (BM - 1);
+  for (int c = 0; c < 4; ++c) {
+    const int j = 32 * wave + 8 * c + (lane >> 3);
+    const int piece = (lane & 7) ^ ((j >> 1) & 7);
     const int q = m0 + j;
     const RowPos r = decode_row(p, q < 0 ? 0 : q);
     const bool ok = q >= 0 && r.ok;
     const int x = r.xbase - p.off_x;
-    s_base[c] = ((r.rowbase + r.ybase * r.SW + x) * p.ld_src + 8 * o) * ES;
+    s_base[c] = (r.rowbase + r.ybase * r.SW + x) * p.ld_src * ES + 16 * piece;
     int v = 0;
     for (int ty = 0; ty < 3; ++ty)
       if (ok && (unsigned)(r.ybase + ty * p.tsign) < (unsigned)r.SH) v |= 1 << ty;
     s_pitch[c] = (p.tsign * r.SW * p.ld_src * ES) | v;
   }
-  // weight tile: slot 64 * hp + lane of plane o <-> weight row (slot - 2 o) & 127
-  const int b_n = n0 + ((64 * hp + lane - 2 * o) & (BN - 1));
-  const int b_dma = b_n < w_rows ? (b_n * w_ld8 + o) * 16 : PP_BUF_OOB;
+  const int b_row = 16 * wave + (lane >> 2);
+  const int b_n = n0 + b_row;
+  const int b_dma = b_n < w_rows ? (b_n * w_ld8 + ((lane & 3) ^ ((b_row >> 2) & 3))) * 16 : PP_BUF_OOB;
   const int b_tap = w_rows * w_ld8 * 16;
 
   unsigned f_valid = 0;
@@ -992,19 +995,18 @@ __global__ __launch_bounds__(512, 1) void igemm4x_kernel(
 
   auto dma_a = [&](int g, uint4* st) {  // the gathered tile of group g -> stage st
     const int ty = g % 3, chunk = g / 3;
-    uint4* const hi = st + o * BM + 128 * hp;
+    uint4* const dst = st + 8 * 32 * wave;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < 4; ++c) {
       int vo = s_base[c] + __mul24(ty, s_pitch[c] & ~15) + chunk * (BK * ES);
       vo = ((s_pitch[c] >> ty) & 1) ? vo : PP_BUF_OOB;
-      dma16(rs_a, hi + 64 * c, vo, 0);
-      dma16(rs_a1, hi + AP1 + 64 * c, vo, 0);
+      dma16(rs_a, dst + 64 * c, vo, 0);
     }
   };
   auto dma_b = [&](int g, int tx, uint4* st) {  // the weight tile of tap (group g, tx) -> stage st
     const int ty = g % 3, chunk = g / 3;
     const int b_uni = ((p.w_ty0 + ty) * p.w_kw + tx) * b_tap + chunk * (BK / 8 * 16);
-    uint4* const hi = st + o * BN + 64 * hp;
+    uint4* const hi = st + 4 * 16 * wave;
     dma16(rs_wh, hi, b_dma, b_uni);
     dma16(rs_wl, hi + NO * BN, b_dma, b_uni);
   };
@@ -1024,7 +1026,7 @@ __global__ __launch_bounds__(512, 1) void igemm4x_kernel(
     unsigned a_ok = 0;
 #pragma unroll
     for (int a = 0; a < TM; ++a) a_ok |= (((okm >> (16 * (a & 1))) & 0xffffu) != 0 ? 1u : 0u) << a;
-    mma_step<TM, TN, BM, BN, 1>(acc, Ahi, Ahi + AP1, Bhi, Bhi + NO * BN, wm * 32 * TM + il + dx, wn * 32 * TN + il, h, a_ok, NO * BM);
+    mma_step<TM, TN, BM, BN, 1, 1>(acc, Ahi, Ahi, Bhi, Bhi + NO * BN, wm * 32 * TM + il + dx, wn * 32 * TN + il, h, a_ok, 8 * BM);
   };
   std::integral_constant<int, 0> c0;
   std::integral_constant<int, 1> c1;
@@ -1059,11 +1061,11 @@ __global__ __launch_bounds__(512, 1) void igemm4x_kernel(
     asm volatile("" ::: "memory");
   };
 
-  if (tid == 0) {
-    sA0[NO * BM] = make_uint4(0u, 0u, 0u, 0u);
-    sA0[AP1 + NO * BM] = make_uint4(0u, 0u, 0u, 0u);
-    sA1[NO * BM] = make_uint4(0u, 0u, 0u, 0u);
-    sA1[AP1 + NO * BM] = make_uint4(0u, 0u, 0u, 0u);
+  if (tid == 0) {  // the two all-zero slots (hi, lo = slot ^ 1) behind each gathered stage
+    sA0[8 * BM] = make_uint4(0u, 0u, 0u, 0u);
+    sA0[8 * BM + 1] = make_uint4(0u, 0u, 0u, 0u);
+    sA1[8 * BM] = make_uint4(0u, 0u, 0u, 0u);
+    sA1[8 * BM + 1] = make_uint4(0u, 0u, 0u, 0u);
   }
   // prologue: group 0 and the weight tiles of taps 0, 1
   dma_a(0, sA0);
@@ -1629,11 +1631,15 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
           constexpr int BM4 = 256;
           constexpr size_t smem_bytes = 0;  // (static LDS: one object per stage)
           const int n_tiles_m4 = (p.M + BM4 - 3) / (BM4 - 2);
+          // (one workgroup per CU: a launch of less than two rounds is better off with three 128 x 128 workgroups per CU)
+          static const int dma_min = []() { const char* e = getenv("PP_CONV3_DMA_MIN"); return e ? atoi(e) : 512; }();
+          if (n_tiles_m4 * ((p.Nout + 127) / 128) >= dma_min) {
           p.n_tiles_n = (p.Nout + 127) / 128;
           hipLaunchKernelGGL((igemm4x_kernel<true>), dim3((unsigned)(n_tiles_m4 * p.n_tiles_n)), dim3(512), smem_bytes, st, p, ahi, alo,
                              (unsigned)a_bytes, whi, wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)ohi, (uint2*)olo, w_rows,
                              w_ld8);
           return;
+          }
         }
       }
       if (ahi && op)

@@ -36,6 +36,30 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned short* lds, int elem_of
   return *reinterpret_cast<bf16x8*>(&v);
 }
 
+// LDS slot (in 16-byte units) of k-octet o of tile row `row`.  LAY 0: the rotated plane image the register-staged kernels write
+// (one plane per pointer: slot o BM + ((row + 2 o) mod BM)).  LAY 1 (igemm4x, filled by LDS-DMA in full 128-byte lines): the
+// gathered tile row-major, eight pieces per row [hi0 lo0 hi1 lo1 ...] with the piece index XOR-ed by (row / 2) mod 8 (hi and lo
+// of an octet are slots s and s ^ 1 of ONE region); the weight tile row-major per plane, four pieces per row XOR-ed by
+// (row / 4) mod 4.  Either way 16 consecutive rows of one octet fall into 16 different 16-byte bank groups.
+template <int BM_, int LAY>
+__device__ __forceinline__ int pf_slot_a(int row, int o) {
+  if constexpr (LAY == 0) {
+    return o * BM_ + ((row + 2 * o) & (BM_ - 1));
+  } else {
+    const int r = row & (BM_ - 1);
+    return 8 * r + ((2 * o) ^ ((r >> 1) & 7));
+  }
+}
+template <int BN_, int LAY>
+__device__ __forceinline__ int pf_slot_b(int n, int o) {
+  if constexpr (LAY == 0) {
+    return o * BN_ + ((n + 2 * o) & (BN_ - 1));
+  } else {
+    const int r = n & (BN_ - 1);
+    return 4 * r + (o ^ ((r >> 2) & 3));
+  }
+}
+
 #if PP_FMT == 1
 #include "p16.h"
 // E8M0 scales of the scaled MFMA in ONE register: byte 0 (opsel 0) = 115 = 2^-12 for the gathered operand, byte 1 (opsel 1) = 127 = 1
@@ -59,7 +83,7 @@ __device__ __forceinline__ bool fmt_any_nonzero(unsigned hi_or, unsigned lo_or) 
 // One 32-deep k-step of a (32 TM) x (32 TN) block set from the rotated LDS images (row_a / row_b: this lane's first tile row of
 // each operand; bit a of a_ok clear = row block a reads the all-zero slot `a_zero`): cross terms first (their fragments die
 // with them), one row block at a time, then the two f16 half-steps.  HINT: 1 = igemm3x's scheduling hint, 2 = igemm3f's.
-template <int TM, int TN, int BM, int BN, int HINT>
+template <int TM, int TN, int BM, int BN, int HINT, int LAY = 0>
 __device__ __forceinline__ void mma_step(pf_floatx16 (&acc)[TM][TN], const uint4* Ahi, const uint4* Alo, const uint4* Bhi, const uint4* Blo,
                                          int row_a, int row_b, int h, unsigned a_ok = ~0u, int a_zero = 0) {
   {
@@ -69,7 +93,7 @@ __device__ __forceinline__ void mma_step(pf_floatx16 (&acc)[TM][TN], const uint4
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int o = 2 * s + h;
-        const uint4 t = Blo[o * BN + ((row_b + b * 32 + 2 * o) & (BN - 1))];
+        const uint4 t = Blo[pf_slot_b<BN, LAY>(row_b + b * 32, o)];
         bq[b][4 * s] = (int)t.x; bq[b][4 * s + 1] = (int)t.y; bq[b][4 * s + 2] = (int)t.z; bq[b][4 * s + 3] = (int)t.w;
       }
 #pragma unroll
@@ -79,7 +103,7 @@ __device__ __forceinline__ void mma_step(pf_floatx16 (&acc)[TM][TN], const uint4
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int o = 2 * s + h;
-        const uint4 t = Alo[ok ? o * BM + ((row_a + a * 32 + 2 * o) & (BM - 1)) : a_zero];
+        const uint4 t = Alo[(ok ? pf_slot_a<BM, LAY>(row_a + a * 32, o) : a_zero) ^ (LAY ? 1 : 0)];
         aq[4 * s] = (int)t.x; aq[4 * s + 1] = (int)t.y; aq[4 * s + 2] = (int)t.z; aq[4 * s + 3] = (int)t.w;
       }
 #pragma unroll
@@ -93,13 +117,13 @@ __device__ __forceinline__ void mma_step(pf_floatx16 (&acc)[TM][TN], const uint4
     halfx8 bh[TN];
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-      uint4 t = Bhi[o * BN + ((row_b + b * 32 + 2 * o) & (BN - 1))];
+      uint4 t = Bhi[pf_slot_b<BN, LAY>(row_b + b * 32, o)];
       bh[b] = *reinterpret_cast<halfx8*>(&t);
     }
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
       const bool ok = (a_ok >> a) & 1u;
-      uint4 t = Ahi[ok ? o * BM + ((row_a + a * 32 + 2 * o) & (BM - 1)) : a_zero];
+      uint4 t = Ahi[ok ? pf_slot_a<BM, LAY>(row_a + a * 32, o) : a_zero];
       const halfx8 ah = *reinterpret_cast<halfx8*>(&t);
 #pragma unroll
       for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[b], acc[a][b], 0, 0, 0);
@@ -192,7 +216,7 @@ __device__ __forceinline__ void fmt_value2(unsigned hi2, unsigned lo2, float* e0
 __device__ __forceinline__ bool fmt_pos(unsigned hi16) { return (short)(unsigned short)hi16 > 0; }  // (bf16 keeps the f32 exponent range)
 __device__ __forceinline__ bool fmt_any_nonzero(unsigned hi_or, unsigned lo_or) { return ((hi_or | lo_or) & 0x7fff7fffu) != 0u; }
 
-template <int TM, int TN, int BM, int BN, int HINT>
+template <int TM, int TN, int BM, int BN, int HINT, int LAY = 0>
 __device__ __forceinline__ void mma_step(pf_floatx16 (&acc)[TM][TN], const uint4* Ahi, const uint4* Alo, const uint4* Bhi, const uint4* Blo,
                                          int row_a, int row_b, int h, unsigned a_ok = ~0u, int a_zero = 0) {
 #pragma unroll
@@ -204,7 +228,7 @@ __device__ __forceinline__ void mma_step(pf_floatx16 (&acc)[TM][TN], const uint4
     bf16x8 bh[TN], bl[TN];
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-      const int slot = o * BN + ((row_b + b * 32 + 2 * o) & (BN - 1));
+      const int slot = pf_slot_b<BN, LAY>(row_b + b * 32, o);
       uint4 t = Bhi[slot];
       bh[b] = *reinterpret_cast<bf16x8*>(&t);
       t = Blo[slot];
@@ -218,10 +242,10 @@ __device__ __forceinline__ void mma_step(pf_floatx16 (&acc)[TM][TN], const uint4
         const int a = a0 + aa;
         const bool ok = (a_ok >> a) & 1u;
         // padded taps read the all-zero slot: one address select per fragment
-        const int slot = ok ? o * BM + ((row_a + a * 32 + 2 * o) & (BM - 1)) : a_zero;
+        const int slot = ok ? pf_slot_a<BM, LAY>(row_a + a * 32, o) : a_zero;
         uint4 t = Ahi[slot];
         ah[aa] = *reinterpret_cast<bf16x8*>(&t);
-        t = Alo[slot];
+        t = Alo[slot ^ (LAY ? 1 : 0)];
         al[aa] = *reinterpret_cast<bf16x8*>(&t);
       }
 #pragma unroll
