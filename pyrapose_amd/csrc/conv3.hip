@@ -670,7 +670,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
   const int lbs = xcd_remap((int)blockIdx.x, (int)gridDim.x);
   const int split = lbs % splits, lb = lbs / splits;
   const int tile_n = lb % p.n_tiles_n, tile_m = lb / p.n_tiles_n;
-  const int m0 = tile_m * (BM - 2) - 1, n0 = tile_n * BN;  // tile row j <-> output row m0 + j; rows 0 and BM - 1 are halo only
+  const int m0 = p.m_off + tile_m * (BM - 2) - 1, n0 = tile_n * BN;  // tile row j <-> output row m0 + j; rows 0 and BM - 1 are halo only
   const int oct = tid & 3, r0 = tid >> 2;
   const int il = lane & 31, h = lane >> 5;
   const int n_chunks = p.Cred / BK;
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
   }
   // rows 0 and BM - 1 of the tile are halo: clear their accumulators' way out by making them out of range
   if (splits > 1) {
-    float* slice = g_ws + (long long)split * p.M * p.ld_out;
+    float* slice = g_ws + (long long)split * (p.M - p.m_off) * p.ld_out;
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
           const int co = n0 + wn * 32 * TN + b * 32 + il;
-          if (row >= 1 && row <= BM - 2 && m < p.M && co < ((p.Nout + 3) & ~3)) slice[(long long)m * p.ld_out + co] = acc[a][b][r];
+          if (row >= 1 && row <= BM - 2 && m < p.M && co < ((p.Nout + 3) & ~3)) slice[(long long)(m - p.m_off) * p.ld_out + co] = acc[a][b][r];
         }
       }
     return;
@@ -1127,10 +1127,12 @@ __global__ void splitk_finish_kernel(const IgemmParams p, int splits, const floa
                                      const float* __restrict__ g_addend, const float* __restrict__ g_mask, float* __restrict__ g_out,
                                      void* __restrict__ g_ohi, void* __restrict__ g_olo) {
   const int n4 = (p.Nout + 3) >> 2;
-  const long long total = (long long)p.M * n4, slice = (long long)p.M * p.ld_out;
+  const int rows = p.M - p.m_off;  // (m_off: the launch covers the rows from there on)
+  const long long total = (long long)rows * n4, slice = (long long)rows * p.ld_out;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int m = (int)(i / n4), co = 4 * (int)(i - (long long)m * n4);
-    const float* w = ws + (long long)m * p.ld_out + co;
+    const int mr = (int)(i / n4), co = 4 * (int)(i - (long long)mr * n4);
+    const int m = p.m_off + mr;
+    const float* w = ws + (long long)mr * p.ld_out + co;
     float4 v = *reinterpret_cast<const float4*>(w);
     for (int s = 1; s < splits; ++s) {
       const float4 q = *reinterpret_cast<const float4*>(w + s * slice);
@@ -1587,7 +1589,7 @@ static void split_capture_pass(hipStream_t st, const IgemmParams& p, void* chi, 
 template <int TM, int TN>
 static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const void* alo, const void* whi, const void* wlo, int w_rows,
                           int w_ld8, void* ohi, void* olo, int splits, float* ws, void* chi = nullptr, void* clo = nullptr,
-                          const unsigned char* flags = nullptr) {
+                          const unsigned char* flags = nullptr, float* ws_any = nullptr, size_t ws_any_bytes = 0, int n_cu = 256) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   p.n_tiles_n = (p.Nout + BN - 1) / BN;
   const int n_tiles_m = (p.M + BM - 1) / BM;
@@ -1631,14 +1633,46 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
           constexpr int BM4 = 256;
           constexpr size_t smem_bytes = 0;  // (static LDS: one object per stage)
           const int n_tiles_m4 = (p.M + BM4 - 3) / (BM4 - 2);
+          const int ntn = (p.Nout + 127) / 128;
           // (one workgroup per CU: a launch of less than two rounds is better off with three 128 x 128 workgroups per CU)
           static const int dma_min = []() { const char* e = getenv("PP_CONV3_DMA_MIN"); return e ? atoi(e) : 512; }();
-          if (n_tiles_m4 * ((p.Nout + 127) / 128) >= dma_min) {
-          p.n_tiles_n = (p.Nout + 127) / 128;
-          hipLaunchKernelGGL((igemm4x_kernel<true>), dim3((unsigned)(n_tiles_m4 * p.n_tiles_n)), dim3(512), smem_bytes, st, p, ahi, alo,
-                             (unsigned)a_bytes, whi, wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)ohi, (uint2*)olo, w_rows,
-                             w_ld8);
-          return;
+          if (n_tiles_m4 * ntn >= dma_min) {
+            // Whole rounds of 256 x 128 tiles go to igemm4x; with one workgroup per CU a last, partly filled round would cost a
+            // full round's time, so the rows of that round are a second launch: 128 x 128 tiles of igemm3x with the reduction
+            // split over enough workgroups to fill the chip once (partial sums -> scratch, splitk_finish_kernel writes the rows)
+            static const bool tail_on = []() { const char* e = getenv("PP_CONV3_DMA_TAIL"); return !(e && e[0] == '0'); }();
+            int full_rt = n_tiles_m4;
+            const int rounds = (n_tiles_m4 * ntn) / n_cu;
+            if (tail_on && (n_tiles_m4 * ntn) % n_cu != 0 && rounds >= 1 && ws_any != nullptr) full_rt = rounds * n_cu / ntn;
+            const int m_split = full_rt * (BM4 - 2);
+            int tail_splits = 0;
+            if (full_rt < n_tiles_m4) {
+              const int rem = p.M - m_split;
+              const int n_rt = (rem + BM - 3) / (BM - 2);
+              const int groups = p.kh * (p.Cred / 32);
+              int sp = (3 * n_cu + n_rt * ntn - 1) / (n_rt * ntn);  // ~ one full round of three workgroups per CU
+              while (sp > 1 && (groups / sp < 4 || (size_t)sp * rem * p.ld_out * 4 > ws_any_bytes)) --sp;
+              if (sp > 1) tail_splits = sp;
+              else full_rt = n_tiles_m4;  // (no room to split: everything in the one launch)
+            }
+            p.n_tiles_n = ntn;
+            hipLaunchKernelGGL((igemm4x_kernel<true>), dim3((unsigned)(full_rt * ntn)), dim3(512), 0, st, p, ahi, alo, (unsigned)a_bytes, whi, wlo,
+                               (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)ohi, (uint2*)olo, w_rows, w_ld8);
+            if (tail_splits > 1) {
+              IgemmParams q = p;
+              q.m_off = full_rt * (BM4 - 2);
+              const int rem = q.M - q.m_off;
+              const int n_rt = (rem + BM - 3) / (BM - 2);
+              hipLaunchKernelGGL((igemm3x_kernel<TM, TN, false, true, false>), dim3((unsigned)(n_rt * ntn * tail_splits)), dim3(256), 0, st, q, ahi,
+                                 alo, (unsigned)a_bytes, whi, wlo, (unsigned)w_bytes, q.bias, q.addend, q.mask_src, q.out, (uint2*)nullptr,
+                                 (uint2*)nullptr, w_rows, w_ld8, tail_splits, ws_any, nullptr, nullptr, (const unsigned char*)nullptr, skip_halo);
+              const long long total = (long long)rem * ((q.Nout + 3) >> 2);
+              long long blocks = (total + 255) / 256;
+              if (blocks > (long long)n_cu * 8) blocks = (long long)n_cu * 8;
+              hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, st, q, tail_splits, (const float*)ws_any, q.bias, q.addend,
+                                 q.mask_src, q.out, ohi, olo);
+            }
+            return;
           }
         }
       }
@@ -1747,7 +1781,9 @@ static void dispatch3(pp_ctx* ctx, IgemmParams& p, const void* ahi, const void* 
             64 * tn, splits, (int)may_split, (int)(ctx->ws != nullptr), (int)(ohi != nullptr), (int)(p.out != nullptr));
   float* ws = splits > 1 ? ctx->ws : nullptr;
   if (tm == 4) launch_igemm3<4, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo, flags);
-  else if (tm == 2 && tn == 2) launch_igemm3<2, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo, flags);
+  else if (tm == 2 && tn == 2)
+    launch_igemm3<2, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo, flags, ctx->ws, (size_t)ctx->ws_bytes,
+                        ctx->n_cu > 0 ? ctx->n_cu : 256);
   else if (tm == 1 && tn == 2) launch_igemm3<1, 2>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo, flags);
   else if (tm == 2 && tn == 1) launch_igemm3<2, 1>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo, flags);
   else launch_igemm3<1, 1>(ctx->stream, p, ahi, alo, whi, wlo, w_rows, w_ld8, ohi, olo, splits, ws, chi, clo, flags);

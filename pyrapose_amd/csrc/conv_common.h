@@ -47,6 +47,8 @@ struct IgemmParams {
   const void* add_lo;
   const void* mask_hi;
   int x_ty_inner;  // igemm3x: loop order of the (kernel row, channel chunk) groups
+  int m_off;       // igemm3x / splitk_finish_kernel: first output row of THIS launch (the rows below belong to another launch:
+                   // the remainder of a launch whose full rounds igemm4x_kernel took); split-K slices hold rows m_off .. M - 1
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8, each with a private L2).
