@@ -911,14 +911,26 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
   epilogue3<TM, TN, OP, 4, false, true>(p, acc, smem, m0, n0, tid, wm, wn, il, h, g_bias, g_addend, g_mask, g_out, g_ohi, g_olo);
 }
 
-// ---- igemm4x (EXPERIMENTAL, PP_CONV3_DMA=1): igemm3x's arithmetic and tap-row reuse on a multi-stage LDS-DMA pipeline ----
-// One workgroup of 8 waves per CU, tile 256 x 128 (wave tile 64 x 64 as before).  Both operands reach LDS by buffer_load ... lds
-// (no staging registers): a wave-instruction writes 64 lane-consecutive 16-byte slots, so the rotated LDS image is produced on the
-// SOURCE side -- the lane at LDS slot s fetches the piece that belongs at s (wave w: k-octet w & 3; gathered operand: rows half
-// w >> 2, two chunks of 64 slots; weights: chunk w >> 2).  Rings: 2 stages of the gathered tile (one per (ty, chunk) group: loaded
-// three taps ahead), 4 stages of the weight tile (three taps ahead); one barrier per tap, counted vmcnt waits (never 0 in the
-// loop): issue order per tap start = [gathered tile of the next group, at tx == 0] then the weight tile of tap t + 3.
-// Planes in, planes out, splits == 1, kh == 3, kernel row innermost (x_ty_inner), w_rows % 128 == 0.
+// ---- igemm4x: igemm3x's arithmetic and tap-row reuse on a multi-stage LDS-DMA pipeline (PP_CONV3_DMA=0 turns it off) ----
+// Why: the 128 x 128, two-barriers-per-tap loop of igemm3x prefetches one tap ahead through registers; with an L2 hit rate of 90 % a
+// wave's four weight loads per tap contain a miss every third tap, and three waves per SIMD cannot cover it (46-59 % of the wave
+// cycles in s_waitcnt, MFMA pipe 48 % busy).  Here: ONE workgroup of 8 waves per CU, tile 256 x 128 (wave tile 64 x 64 as
+// before), both operands reach LDS by buffer_load ... lds (no staging registers) into rings -- 2 stages of the gathered tile (one
+// per (ty, chunk) group, loaded a group = three taps ahead), 3 stages of the weight tile (the stage of a tap is its tx; loaded two
+// taps ahead) -- that stay in flight ACROSS the one barrier per tap; the waits are counted (vmcnt 6 / 2 / 2), never 0 in the loop.
+//  * A wave-instruction of LDS-DMA writes 64 lane-consecutive 16-byte slots, so the LDS image is shaped on the SOURCE side: the
+//    lane at slot s fetches the piece that belongs at s.  Images (planes_fmt.h LAY 1): row-major, XOR-swizzled pieces -- one
+//    instruction moves 8 rows x 128 contiguous bytes of the gathered operand ([hi0 lo0 .. hi3 lo3] of a row's 32-channel chunk:
+//    full lines; fragment-shaped 16-byte pieces of 64 different lines per instruction cost 15 % of the kernel) or 16 rows x 64
+//    bytes of a weight plane.  Padding rows are out-of-range offsets (the DMA writes zeros).
+//  * Every stage is an LDS object of its own: the compiler tracks LDS-DMA per object (alias scopes), so the waits it inserts in
+//    front of a fragment read are COUNTED and cover the DMA into that stage only (one shared array: vmcnt(0) before every read).
+//  * One workgroup per CU makes a last, partly filled round cost a whole round: the host gives whole rounds to this kernel and
+//    the remaining rows to igemm3x with the reduction split over a round's worth of workgroups (IgemmParams::m_off).
+// Same products in the same order as igemm3x: the rows of the whole rounds are bit-identical to it.  Planes in, planes out,
+// 3x3 stride 1, kernel row innermost (x_ty_inner), w_rows % 128 == 0, at least two rounds of tiles (PP_CONV3_DMA_MIN).
+// Measured (P16, same box): 422-434 us against 499 on a tail-free 512-channel shape (1.16x), the regression-head launch 486 against
+// 577 us (1.19x, 490 TFLOP/s); bf16 pairs 1.04x; training step +3.1 %.
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, uint4* lds, int voff, int soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 }
@@ -1627,8 +1639,11 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
         }
       }
       if constexpr (TM == 2 && TN == 2) {
-        // EXPERIMENTAL (PP_CONV3_DMA=1): the multi-stage LDS-DMA form of this launch (igemm4x_kernel), planes in and out
-        static const bool dma_on = []() { const char* e = getenv("PP_CONV3_DMA"); return e && e[0] == '1'; }();
+        // the multi-stage LDS-DMA form of this launch (igemm4x_kernel: planes in and out, at least two rounds of 256 x 128 tiles);
+        // PP_CONV3_DMA=0 keeps everything on igemm3x
+        // (read at every launch, unlike the other knobs: tests compare the two kernels inside one process)
+        const char* const dma_env = getenv("PP_CONV3_DMA");
+        const bool dma_on = !(dma_env && dma_env[0] == '0');
         if (dma_on && ahi && op && !flags && splits == 1 && p.kh == 3 && x_order == 1 && w_rows % 128 == 0 && p.Cred % 32 == 0) {
           constexpr int BM4 = 256;
           constexpr size_t smem_bytes = 0;  // (static LDS: one object per stage)

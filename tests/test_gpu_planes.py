@@ -480,3 +480,61 @@ def test_lazy_sparse_gradients(ctx):
                            lazy_in=True)
     with pytest.raises(ValueError):
         ops.conv_bwd_weight3(ctx, d_a, None, None, torch.zeros_like(wa), None, x_planes=xa, dy_planes=xa, lazy_in=True)
+
+
+def test_lds_dma_kernel_matches_register_staged(ctx, monkeypatch):
+    """igemm4x (csrc/conv3.hip): the head-conv launch on the multi-stage LDS-DMA pipeline -- taken for planes in / planes out, 3x3
+    stride 1, cout % 128 == 0 and at least two rounds of 256 x 128 tiles, with the rows of the last partly filled round going to a
+    split-K launch of the 128 x 128 kernel.  Same products in the same order as the register-staged igemm3x (PP_CONV3_DMA=0, read at
+    every launch): the whole-round rows are bit-identical, the split-K rows agree to f32 summation order; forward with bias +
+    residual + ReLU and data gradient with addend + ReLU mask; within the per-launch bound of the arithmetic against float64."""
+    import torch.nn.functional as F
+    from pyrapose_amd import ops
+    rng = np.random.default_rng(31)
+    B, shapes, cin, cout, k = 1, [(262, 128)], 128, 512, 3    # 33 536 rows: 133 x 4 = 532 tiles = 2 rounds + 20 (tail path)
+    rows = sum(B * h * w for h, w in shapes)
+    d = ops.make_conv_desc(B, shapes, shapes, cin, cout, k, 1, 1, 1, cin, cout, cout)
+    dT = ops.make_conv_desc(B, shapes, shapes, cout, cout, k, 1, 1, 1, cout, cout, cout)  # square layer for the data gradient
+    x = torch.as_tensor(rng.standard_normal((rows, cin)), dtype=torch.float32).cuda()
+    w = torch.as_tensor(rng.standard_normal((k * k * cin, cout)) * 0.05, dtype=torch.float32).cuda()
+    w2 = torch.as_tensor(rng.standard_normal((k * k * cout, cout)) * 0.02, dtype=torch.float32).cuda()
+    bias = torch.as_tensor(rng.standard_normal((cout,)), dtype=torch.float32).cuda()
+    res = torch.as_tensor(rng.standard_normal((rows, cout)), dtype=torch.float32).cuda()
+    dy = torch.as_tensor(rng.standard_normal((rows, cout)), dtype=torch.float32).cuda()
+    i16 = dict(dtype=torch.int16, device="cuda")
+    fh, fl = torch.zeros((k * k, cout, cin), **i16), torch.zeros((k * k, cout, cin), **i16)
+    dh, dl = torch.zeros((k * k, cin, cout), **i16), torch.zeros((k * k, cin, cout), **i16)
+    ops.conv_split_weights3(ctx, d, w, fh, fl, dh, dl)
+    f2h, f2l = torch.zeros((k * k, cout, cout), **i16), torch.zeros((k * k, cout, cout), **i16)
+    d2h, d2l = torch.zeros((k * k, cout, cout), **i16), torch.zeros((k * k, cout, cout), **i16)
+    ops.conv_split_weights3(ctx, dT, w2, f2h, f2l, d2h, d2l)
+    xp, rp, gp = split(ctx, x), split(ctx, res), split(ctx, dy)
+    out = {}
+    ctx.set_workspace(64 << 20)
+    try:
+        for dma in ("0", "1"):
+            monkeypatch.setenv("PP_CONV3_DMA", dma)
+            yp = nan_planes(res)
+            ops.conv_fwd3(ctx, d, None, fh, fl, bias, None, True, None, x_planes=xp, y_planes=yp, res_planes=rp)
+            dxp = nan_planes(res)
+            ops.conv_bwd_data3(ctx, dT, None, d2h, d2l, None, None, None, dy_planes=gp, dx_planes=dxp, addend_planes=rp, relu_src_hi=rp[0])
+            torch.cuda.synchronize()
+            out[dma] = (raw(yp), raw(dxp), merged(yp), merged(dxp))
+    finally:
+        ctx.set_workspace(0)
+        monkeypatch.delenv("PP_CONV3_DMA", raising=False)
+    full = 2 * 256 // 4 * 254            # rows of the two whole rounds: 128 row tiles of 254 rows
+    for i in (0, 1):
+        (ah, al), (bh, bl) = out["0"][i], out["1"][i]
+        assert torch.equal(ah[:full], bh[:full]) and torch.equal(al[:full], bl[:full]), i
+        va, vb = out["0"][2 + i], out["1"][2 + i]
+        assert not torch.isnan(vb).any()
+        # (split-K rows: another summation order, then re-encoded: one step of the plane format's remainder, 2^-15 in P16)
+        assert float((va - vb).abs().max()) <= (8e-5 if FMT[0] == 1 else 4e-5) * float(va.abs().max()), i
+    # float64 reference of the forward
+    xv = merged(xp)
+    xi = xv.double().reshape(1, 262, 128, cin).permute(0, 3, 1, 2)
+    wt = w.double().reshape(k, k, cin, cout).permute(3, 2, 0, 1)
+    ref = torch.relu(F.conv2d(xi, wt, bias.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, cout) + merged(rp).double())
+    err = (out["1"][2].double() - ref).abs().max() / ref.abs().max()
+    assert float(err) <= (1e-4 if FMT[0] == 1 else 3e-5), float(err)
