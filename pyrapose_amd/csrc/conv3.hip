@@ -1650,15 +1650,22 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
           const int n_tiles_m4 = (p.M + BM4 - 3) / (BM4 - 2);
           const int ntn = (p.Nout + 127) / 128;
           // (one workgroup per CU: a launch of less than two rounds is better off with three 128 x 128 workgroups per CU)
+          // between one and two rounds (the 256-channel heads: 398 tiles) one launch CAN pay in isolation when the second round is
+          // at least half full (PP_CONV3_DMA_FRAC=50: class head 149 us against 162; 1.19 rounds do not: mask head 137 / 115) -- but in
+          // the training step those launches run beside the regression head's on the other lane, and two 115 KB workgroups cannot
+          // share a CU where a 33 KB one fits next to this kernel's: the step LOSES 2.4 % (594 vs 608 images/s).  Off by default.
           static const int dma_min = []() { const char* e = getenv("PP_CONV3_DMA_MIN"); return e ? atoi(e) : 512; }();
-          if (n_tiles_m4 * ntn >= dma_min) {
+          static const int dma_frac = []() { const char* e = getenv("PP_CONV3_DMA_FRAC"); return e ? atoi(e) : 1000; }();  // percent
+          const int n_blk = n_tiles_m4 * ntn;
+          const bool one_and_a_bit = n_blk > n_cu && n_blk < 2 * n_cu && (n_blk - n_cu) * 100 >= dma_frac * n_cu;
+          if (n_blk >= dma_min || one_and_a_bit) {
             // Whole rounds of 256 x 128 tiles go to igemm4x; with one workgroup per CU a last, partly filled round would cost a
             // full round's time, so the rows of that round are a second launch: 128 x 128 tiles of igemm3x with the reduction
             // split over enough workgroups to fill the chip once (partial sums -> scratch, splitk_finish_kernel writes the rows)
             static const bool tail_on = []() { const char* e = getenv("PP_CONV3_DMA_TAIL"); return !(e && e[0] == '0'); }();
             int full_rt = n_tiles_m4;
             const int rounds = (n_tiles_m4 * ntn) / n_cu;
-            if (tail_on && (n_tiles_m4 * ntn) % n_cu != 0 && rounds >= 1 && ws_any != nullptr) full_rt = rounds * n_cu / ntn;
+            if (tail_on && (n_tiles_m4 * ntn) % n_cu != 0 && rounds >= 2 && ws_any != nullptr) full_rt = rounds * n_cu / ntn;
             const int m_split = full_rt * (BM4 - 2);
             int tail_splits = 0;
             if (full_rt < n_tiles_m4) {
