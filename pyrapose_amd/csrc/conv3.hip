@@ -934,7 +934,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, uint4* lds, int voff, int soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 }
-template <bool OP>
+template <bool OP, int VAR = 0>
 __global__ __launch_bounds__(512, 1) void igemm4x_kernel(
     const IgemmParams p, const void* __restrict__ g_a, const void* __restrict__ g_a1, unsigned a_bytes, const void* __restrict__ g_whi,
     const void* __restrict__ g_wlo, unsigned w_bytes, const float* __restrict__ g_bias, const float* __restrict__ g_addend,
@@ -1038,7 +1038,9 @@ __global__ __launch_bounds__(512, 1) void igemm4x_kernel(
     unsigned a_ok = 0;
 #pragma unroll
     for (int a = 0; a < TM; ++a) a_ok |= (((okm >> (16 * (a & 1))) & 0xffffu) != 0 ? 1u : 0u) << a;
-    mma_step<TM, TN, BM, BN, 1, 1>(acc, Ahi, Ahi, Bhi, Bhi + NO * BN, wm * 32 * TM + il + dx, wn * 32 * TN + il, h, a_ok, 8 * BM);
+    if (VAR & 2) __builtin_amdgcn_s_setprio(1);
+    mma_step<TM, TN, BM, BN, (VAR & 4) ? 2 : ((VAR & 1) ? 0 : 1), 1>(acc, Ahi, Ahi, Bhi, Bhi + NO * BN, wm * 32 * TM + il + dx, wn * 32 * TN + il, h, a_ok, 8 * BM);
+    if (VAR & 2) __builtin_amdgcn_s_setprio(0);
   };
   std::integral_constant<int, 0> c0;
   std::integral_constant<int, 1> c1;
@@ -1678,8 +1680,19 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
               else full_rt = n_tiles_m4;  // (no room to split: everything in the one launch)
             }
             p.n_tiles_n = ntn;
-            hipLaunchKernelGGL((igemm4x_kernel<true>), dim3((unsigned)(full_rt * ntn)), dim3(512), 0, st, p, ahi, alo, (unsigned)a_bytes, whi, wlo,
-                               (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)ohi, (uint2*)olo, w_rows, w_ld8);
+            // scheduling variants (measured on the regression-head launch, P16): 1 = no iglp_opt hint in the k-step (default: 442 us
+            // against 465 with igemm3x's hint, 0), 2 / 3 = s_setprio around the MFMAs of 0 / 1 (466 / 461), 4 = igemm3f's sched_barrier
+            static const int var = []() { const char* e = getenv("PP_CONV3_DMA_VAR"); return e ? atoi(e) : 1; }();
+            auto go4 = [&](auto v) {
+              hipLaunchKernelGGL((igemm4x_kernel<true, decltype(v)::value>), dim3((unsigned)(full_rt * ntn)), dim3(512), 0, st, p, ahi, alo,
+                                 (unsigned)a_bytes, whi, wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)ohi, (uint2*)olo, w_rows,
+                                 w_ld8);
+            };
+            if (var == 0) go4(std::integral_constant<int, 0>{});
+            else if (var == 2) go4(std::integral_constant<int, 2>{});
+            else if (var == 3) go4(std::integral_constant<int, 3>{});
+            else if (var == 4) go4(std::integral_constant<int, 4>{});
+            else go4(std::integral_constant<int, 1>{});
             if (tail_splits > 1) {
               IgemmParams q = p;
               q.m_off = full_rt * (BM4 - 2);
