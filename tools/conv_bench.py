@@ -64,8 +64,10 @@ def main():
     ctx = ops.Context(0)
     if args.fmt:
         ops.set_planes_format(ctx, args.fmt)
-    if os.environ.get("PP_SPLITK_MB"):
-        ctx.set_workspace(int(os.environ["PP_SPLITK_MB"]) << 20)
+    # (the engine gives every launch lane 256 MB of scratch: split-K of small layers, the split-K remainder of an igemm4x launch)
+    ws_mb = int(os.environ.get("PP_SPLITK_MB", "256"))
+    if ws_mb > 0:
+        ctx.set_workspace(ws_mb << 20)
     for name in args.shape.split(","):
         if name.startswith("c:"):  # c:B:H:W:cin:cout:k -- one level, stride 1, "same" padding (tile-count experiments)
             B_, H_, W_, ci_, co_, k_ = [int(v) for v in name[2:].split(":")]
