@@ -597,9 +597,10 @@ def main_worker(args):
             kname = {"bf16x3": "conv implicit-GEMM family (igemm3x / igemm3f fwd + bwd-data, wgrad3f): 3 x v_mfma_f32_32x32x16_bf16 per product, f32 accumulate",
                      "f16c8": "conv implicit-GEMM family (igemm3x / igemm3f fwd + bwd-data, wgrad3f) on P16 planes: per 32-deep step 2 x "
                               "v_mfma_f32_32x32x16_f16 + 1 x v_mfma_scale_f32_32x32x64_f8f6f4 (e5m2 cross terms) = 2 MFMA units per product"}.get(
-                mode, "conv implicit-GEMM family (igemm3x / igemm3f fwd + bwd-data, wgrad3f), one source compiled per plane format: backbone = "
-                      "3 x v_mfma_f32_32x32x16_bf16 per product (bf16x3); FPN + heads = v_mfma_f32_32x32x16_f16 + half a "
-                      "v_mfma_scale_f32_32x32x64_f8f6f4 per 16-deep step (f16c8: 2 MFMA units per product)")
+                mode, "conv implicit-GEMM family (igemm4x = the multi-stage LDS-DMA form of the 512-wide head launches, igemm3x / igemm3f fwd + "
+                      "bwd-data, wgrad3f), one source compiled per plane format: backbone = 3 x v_mfma_f32_32x32x16_bf16 per product "
+                      "(bf16x3); FPN + heads = v_mfma_f32_32x32x16_f16 + half a v_mfma_scale_f32_32x32x64_f8f6f4 per 16-deep step "
+                      "(f16c8: 2 MFMA units per product)")
         else:
             peak, kname = PEAK_F32_MFMA_TFLOPS, "conv implicit-GEMM family (igemm fwd/bwd-data + wgrad): v_mfma_f32_32x32x2_f32"
         mm = roof["executed_units"] / roof["executed"]  # MFMA issue slots (16-deep f16/bf16 MFMA equivalents) per executed product
