@@ -1667,7 +1667,10 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
             static const bool tail_on = []() { const char* e = getenv("PP_CONV3_DMA_TAIL"); return !(e && e[0] == '0'); }();
             int full_rt = n_tiles_m4;
             const int rounds = (n_tiles_m4 * ntn) / n_cu;
-            if (tail_on && (n_tiles_m4 * ntn) % n_cu != 0 && rounds >= 2 && ws_any != nullptr) full_rt = rounds * n_cu / ntn;
+            // (a last round that is mostly full stays in the one launch: 720 x 540 gives 1 016 tiles = 3.97 rounds)
+            static const int tail_frac = []() { const char* e = getenv("PP_CONV3_DMA_TAIL_FRAC"); return e ? atoi(e) : 60; }();  // percent
+            const int last = (n_tiles_m4 * ntn) % n_cu;
+            if (tail_on && last != 0 && last * 100 < tail_frac * n_cu && rounds >= 2 && ws_any != nullptr) full_rt = rounds * n_cu / ntn;
             const int m_split = full_rt * (BM4 - 2);
             int tail_splits = 0;
             if (full_rt < n_tiles_m4) {
