@@ -940,7 +940,7 @@ __global__ __launch_bounds__(512, 1) void igemm4x_kernel(
     const void* __restrict__ g_wlo, unsigned w_bytes, const float* __restrict__ g_bias, const float* __restrict__ g_addend,
     const float* __restrict__ g_mask, float* __restrict__ g_out, uint2* __restrict__ g_ohi, uint2* __restrict__ g_olo, int w_rows, int w_ld8) {
   constexpr int TM = 2, TN = 2, NWM = 4, BM = 32 * TM * NWM, BN = 128, BK = 32, NO = BK / 8, ES = 4;
-  constexpr int AP1 = NO * BM + 1, A_STAGE = 2 * AP1, B_STAGE = 2 * NO * BN;
+  constexpr int A_STAGE = 8 * BM + 2, B_STAGE = 2 * NO * BN;  // (gathered: 8 pieces per row + the two zero slots; weights: hi + lo regions)
   // every stage is an LDS object of its own: the compiler's LDS-DMA tracking (alias scopes per object) then inserts COUNTED vmcnt
   // waits in front of a fragment read -- for the DMA into that stage only -- instead of draining everything in flight
   __shared__ __attribute__((aligned(16))) uint4 sA0[A_STAGE];
@@ -962,7 +962,7 @@ __global__ __launch_bounds__(512, 1) void igemm4x_kernel(
   const int G = p.kh * n_chunks;  // groups: (chunk, ty), ty innermost
 
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_a), 0, a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_a1), 0, a_bytes - 16, 0x00020000);
+  (void)g_a1;  // (packed planes: the lo halves are pieces of the same 128-byte chunks, reached through g_a)
   const __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_whi), 0, w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_wlo), 0, w_bytes, 0x00020000);
 
@@ -1044,9 +1044,6 @@ __global__ __launch_bounds__(512, 1) void igemm4x_kernel(
   };
   std::integral_constant<int, 0> c0;
   std::integral_constant<int, 1> c1;
-  std::integral_constant<int, 2> c2;
-  std::integral_constant<int, 4> c4;
-  std::integral_constant<int, 6> c6;
   // Weight ring of THREE stages: the stage of a tap is its tx (compile time without unrolling over groups), the tile of tap t + 2
   // goes into the stage tap t - 1 has just left; gathered ring of two stages (unrolled over two groups), loaded one group ahead.
   // Issue order at a tap's start: [gathered tile of the next group, at tx == 0], weight tile of tap t + 2.  At the end of tap t the
@@ -1093,7 +1090,6 @@ __global__ __launch_bounds__(512, 1) void igemm4x_kernel(
     if (g + 1 >= G) break;
     group(g + 1, c1);
   }
-  (void)c2; (void)c4; (void)c6;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the look-ahead loads of a group that never comes: landed before LDS is reused
   __syncthreads();
   epilogue3<TM, TN, OP, 4, false, true, false, NWM, 512>(p, acc, sA0, m0, n0, tid, wm, wn, il, h, g_bias, g_addend, g_mask, g_out, g_ohi, g_olo);
@@ -1648,7 +1644,6 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
         const bool dma_on = !(dma_env && dma_env[0] == '0');
         if (dma_on && ahi && op && !flags && splits == 1 && p.kh == 3 && x_order == 1 && w_rows % 128 == 0 && p.Cred % 32 == 0) {
           constexpr int BM4 = 256;
-          constexpr size_t smem_bytes = 0;  // (static LDS: one object per stage)
           const int n_tiles_m4 = (p.M + BM4 - 3) / (BM4 - 2);
           const int ntn = (p.Nout + 127) / 128;
           // (one workgroup per CU: a launch of less than two rounds is better off with three 128 x 128 workgroups per CU)
