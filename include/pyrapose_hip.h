@@ -198,19 +198,6 @@ int pp_grad_scale_from_counts(pp_ctx* ctx, const int* counts_dev, int n_counts, 
 int pp_split_planes_scaled_bf16x3(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo, const float* scale_dev);
 int pp_ctx_set_grad_scale(pp_ctx* ctx, const float* scale2_dev);
 
-/* ---- "f16c8" arithmetic (csrc/conv2.hip): x*w ~= x_hi*w_hi (f16 MFMA) + (x_hi8*w_lo8 + x_lo8*w_hi8) * 2^-12 (block-scaled e5m2
- * MFMA at twice the rate): two matrix-core units per product instead of the three of bf16x3, ~3e-5 relative error per
- * reduction.  Replaces the same Conv2D layers (models/retinanet.py:101-131 and the other 3x3 stride-1 convs of the graph).
- * H16L8 storage ("hl") of a tensor [rows][ld], ld % 64 == 0: rows * ld * 3 bytes, 192-byte groups of 64 channels = 128 bytes
- * of f16 hi values in channel order + 64 e5m2 bytes of (value - hi) * 2^12, ordered [octets 0,2,4,6 | octets 1,3,5,7] of the
- * group.  Values beyond +-65504 saturate. */
-int pp_split_h16l8(pp_ctx* ctx, long long rows, int ld, const float* src, void* dst);
-int pp_merge_h16l8(pp_ctx* ctx, long long rows, int ld, const void* src, float* dst);
-/* weights f32 HWIO [tap * cin + ci][ld_w] -> hl in the forward layout [tap][cout][cin] and / or the bwd-data layout
- * [tap][cin][cout rounded up to 64] (either may be NULL); cin % 64 == 0 */
-int pp_conv_split_weights_f16c8(pp_ctx* ctx, const pp_conv_desc* d, const float* w, void* fwd, void* dgrad);
-/* 3-wide stride-1 'same' convolution of an hl tensor (ld_x == cin): y (f32 [rows][ld_y]) = conv(x, w) + bias, optional ReLU */
-int pp_conv2d_nhwc_fwd_f16c8(pp_ctx* ctx, const pp_conv_desc* d, const void* x_hl, const void* w_hl, const float* bias, int relu, float* y);
 int pp_conv2d_nhwc_fwd_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const void* x_hi, const void* x_lo,
                               const void* w_fwd_hi, const void* w_fwd_lo, const float* bias, const float* residual,
                               int ld_res, int relu, float* y, void* y_hi, void* y_lo);

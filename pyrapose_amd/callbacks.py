@@ -2,9 +2,11 @@
 ModelCheckpoint (keras.callbacks.ModelCheckpoint as configured there: one file per epoch, '{backbone}_{dataset}_{epoch:02d}.h5'),
 RedirectModel (callbacks/common.py:4-47) and ReduceLROnPlateau (monitor='loss', factor 0.1, patience 2).
 
-Checkpoint files keep whatever name the caller formats (the reference uses '.h5') but hold the numpy container of
-PyraPoseModel.save_weights (keys '<layer>/kernel' in Keras HWIO layout, '<layer>/bias', '<bn>/gamma|beta|moving_*'):
-h5py is not available to this image; load_weights recognises the container by its magic bytes, not by the extension."""
+Checkpoint files: like Keras, ModelCheckpoint writes FULL models unless save_weights_only is set -- PyraPoseModel.save: HDF5 in
+Keras-2.3.1's `model.save` layout ('model_weights' + 'optimizer_weights' with Adam's iterations / m / v + `training_config`) under
+the reference's '.h5' names, written by utils/hdf5_lite.py (no h5py in this image); `models.load_model` of such a file resumes
+training with the optimizer state (bin/train.py:336-343).  Other extensions, or PP_CHECKPOINT_NPZ=1, give the numpy container
+with the same content; either is recognised by content, not by extension."""
 from .models.model import ReduceLROnPlateau  # noqa: F401  (re-export under the callbacks namespace)
 
 
@@ -45,6 +47,7 @@ class ModelCheckpoint(Callback):
         super(ModelCheckpoint, self).__init__()
         self.filepath, self.monitor, self.verbose = filepath, monitor, verbose
         self.save_best_only, self.period, self.epochs_since_last_save = save_best_only, int(period), 0
+        self.save_weights_only = bool(save_weights_only)
         if mode not in ("auto", "min", "max"):
             mode = "auto"
         if mode == "auto":
@@ -66,7 +69,10 @@ class ModelCheckpoint(Callback):
             self.best = cur
         if self.verbose:
             print("\nEpoch %05d: saving model to %s" % (epoch + 1, path))
-        self.model.save(path)
+        if self.save_weights_only:
+            self.model.save_weights(path)
+        else:
+            self.model.save(path)
 
 
 class RedirectModel(Callback):

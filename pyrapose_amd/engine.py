@@ -208,6 +208,48 @@ class ParamStore(object):
         return W
 
 
+    def trainable_keys(self):
+        """'<layer>/kernel' and '<layer>/bias' of every tensor the optimizer updates, in layout (= graph) order"""
+        return [k for k, e in self.entries.items() if e["trainable"]]
+
+    def export_trainable(self, buf):
+        """the slices of a flat per-parameter buffer (Adam m / v) that belong to trainable tensors, in the Keras layout of export()"""
+        host = buf.detach().cpu().numpy()
+        out = OrderedDict()
+        for key in self.trainable_keys():
+            name, var = key.rsplit("/", 1)
+            s, e = self.specs[name], self.entries[key]
+            if var == "kernel":
+                cin_eff = 4 if s.cin == 3 else s.cin
+                k = host[e["offset"]: e["offset"] + e["count"]].reshape(e["rows"], e["ld"])[: s.k * s.k * cin_eff, : s.cout]
+                out[key] = np.ascontiguousarray(k.reshape(s.k, s.k, cin_eff, s.cout)[:, :, : s.cin, :])
+            else:
+                out[key] = host[e["offset"]: e["offset"] + s.cout].copy()
+        return out
+
+    def import_trainable(self, buf, tensors):
+        """the inverse: {key: array in Keras layout} -> the flat buffer (padding stays zero); every trainable key must be there"""
+        host = np.zeros((self.total,), np.float32)
+        for key in self.trainable_keys():
+            name, var = key.rsplit("/", 1)
+            s, e = self.specs[name], self.entries[key]
+            a = np.asarray(tensors[key], np.float32)
+            if var == "kernel":
+                if a.shape != (s.k, s.k, s.cin, s.cout):
+                    raise ValueError("optimizer state of %s: shape %s, expected %s" % (key, a.shape, (s.k, s.k, s.cin, s.cout)))
+                if s.cin == 3:
+                    a = np.concatenate([a, np.zeros((s.k, s.k, 1, s.cout), np.float32)], axis=2)
+                k2 = a.reshape(-1, s.cout)
+                b = np.zeros((e["rows"], e["ld"]), np.float32)
+                b[: k2.shape[0], : s.cout] = k2
+                host[e["offset"]: e["offset"] + e["count"]] = b.reshape(-1)
+            else:
+                if a.shape != (s.cout,):
+                    raise ValueError("optimizer state of %s: shape %s, expected %s" % (key, a.shape, (s.cout,)))
+                host[e["offset"]: e["offset"] + s.cout] = a
+        buf.copy_(torch.from_numpy(host))
+
+
 class Engine(object):
     def __init__(self, ctx, num_classes, batch, height, width, backbone="resnet50", weights=None, train=True, seed=0,
                  lr=1e-5, clipnorm=0.001, freeze_backbone=False, conv_mode=None, pyramid="sparse", anchor_params=None,
@@ -1269,6 +1311,20 @@ class Engine(object):
         if self.grad_sync is not None:
             self.grad_sync.finish()
         self.optimizer_step()
+
+    def export_optimizer_state(self):
+        """{'iterations': steps taken, 'm': {key: array}, 'v': {key: array}} -- Adam's state in the Keras layout of the weights"""
+        assert self.train
+        torch.cuda.synchronize()
+        return dict(iterations=int(self.step_count), m=self.params.export_trainable(self.params.m), v=self.params.export_trainable(self.params.v))
+
+    def load_optimizer_state(self, state):
+        assert self.train
+        torch.cuda.synchronize()  # (host -> device copies on the caller's stream: nothing of a running step may still read m / v)
+        self.params.import_trainable(self.params.m, state["m"])
+        self.params.import_trainable(self.params.v, state["v"])
+        self.step_count = int(state["iterations"])
+        torch.cuda.synchronize()
 
     def losses(self):
         v = self.loss_sums.detach().cpu().numpy()

@@ -42,20 +42,55 @@ def backbone(backbone_name):
 
 
 def load_model(filepath, backbone_name="resnet50", num_classes=None):
-    """models/__init__.py:68-71.  ``filepath`` is an .npz written by ``model.save``; the class count is read from it."""
+    """models/__init__.py:68-71 (`keras.models.load_model`): the model of a snapshot written by `model.save` -- weights, and when
+    the file carries them the compile state (optimizer + losses) and Adam's iterations / moments, so that the next
+    `fit_generator` continues the interrupted run (bin/train.py:336-343).  Also takes a weights-only file (Keras .h5 or the
+    numpy container): the class count is then read from the mask head's bias and the model comes back uncompiled."""
+    import json
+
     import numpy as np
+
+    from .. import losses, optimizers
+    from ..utils import hdf5_lite, keras_names
     from .model import PyraPoseModel
-    with open(filepath, "rb") as f:
-        is_hdf5 = f.read(4) == b"\x89HDF"
-    if is_hdf5:  # a real Keras file: the subset reader + name mapping (utils/hdf5_lite.py, utils/keras_names.py)
-        from ..utils import hdf5_lite, keras_names
+    cfg, state = {}, None
+    if hdf5_lite.is_hdf5(filepath):
         data = keras_names.keras_to_tensors(hdf5_lite.read_keras_weights(filepath))
+        ow, attrs = hdf5_lite.read_optimizer_weights(filepath)
+        if "pyrapose_amd_config" in attrs:
+            cfg = json.loads(bytes(np.asarray(attrs["pyrapose_amd_config"]).tobytes()).rstrip(b"\0").decode("utf-8"))
+        if ow is not None:
+            names = [v.decode("utf-8") if isinstance(v, (bytes, np.bytes_)) else str(v)
+                     for v in np.atleast_1d(attrs.get("pyrapose_amd_optimizer_tensors", []))]
+            vals = list(ow.values())
+            n = (len(vals) - 1) // 3  # Keras' Adam: [iterations] + ms + vs + vhats
+            if names and len(names) != n:
+                raise ValueError("load_model: %d optimizer tensors named, %d stored" % (len(names), n))
+            if not names:  # a file without the name list: positional, in the order of this package's trainable tensors
+                probe = PyraPoseModel(int(cfg.get("num_classes", data["mask_out/bias"].shape[0])), cfg.get("backbone", backbone_name.split("_")[0]),
+                                      pyramid=cfg.get("pyramid", "sparse"))
+                names = [l for l in keras_names.trainable_tensor_order(probe)]
+            state = dict(iterations=int(np.asarray(vals[0]).reshape(-1)[0]), m=dict(zip(names, vals[1:1 + n])), v=dict(zip(names, vals[1 + n:1 + 2 * n])))
     else:
-        data = np.load(filepath)
+        z = np.load(filepath)
+        data = {k: z[k] for k in z.files if not (k.startswith("optimizer/") or k.startswith("config/"))}
+        if "config/json" in z.files:
+            cfg = json.loads(z["config/json"].tobytes().decode("utf-8"))
+        if "optimizer/iterations" in z.files:
+            ms = {k[len("optimizer/m/"):]: z[k] for k in z.files if k.startswith("optimizer/m/")}
+            vs = {k[len("optimizer/v/"):]: z[k] for k in z.files if k.startswith("optimizer/v/")}
+            state = dict(iterations=int(z["optimizer/iterations"]), m=ms, v=vs)
     if num_classes is None:
-        num_classes = int(data["mask_out/bias"].shape[0])
-    m = PyraPoseModel(num_classes, backbone_name.split("_")[0])
+        num_classes = int(cfg.get("num_classes", data["mask_out/bias"].shape[0]))
+    m = PyraPoseModel(num_classes, cfg.get("backbone", backbone_name.split("_")[0]), pyramid=cfg.get("pyramid", "sparse"),
+                      freeze_backbone=bool(cfg.get("freeze_backbone", False)))
     m.load_weights(filepath)
+    if "optimizer" in cfg and "loss" in cfg:
+        mk = {"orthogonal_l1": lambda d: losses.orthogonal_l1(weight=d.get("weight", 0.125), sigma=d.get("sigma", 3.0)),
+              "focal": lambda d: losses.focal(alpha=d.get("alpha", 0.25), gamma=d.get("gamma", 2.0))}
+        m.compile(loss={k: mk[d["kind"]](d) for k, d in cfg["loss"].items()}, optimizer=optimizers.Adam(**cfg["optimizer"]["config"]))
+    if state is not None:
+        m.set_optimizer_state(state)
     return m
 
 

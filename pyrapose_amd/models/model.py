@@ -55,6 +55,7 @@ class PyraPoseModel(object):
         self._weights_version = 0    # bumped by every optimisation step / load_weights
         self._loss = None
         self._optimizer = None
+        self._pending_opt = None     # optimizer state read from a snapshot, waiting for the first training plan
         self.freeze_backbone = freeze_backbone
         self.stop_training = False
         self.layers = [_LayerHandle(s.name, self) for s in arch.all_specs(self.num_classes, backbone, pyramid, na)]
@@ -104,6 +105,9 @@ class PyraPoseModel(object):
                     e.params.m.copy_(prev.params.m)
                     e.params.v.copy_(prev.params.v)
                     e.step_count = prev.step_count
+                elif self._pending_opt is not None:  # resumed from a full-model snapshot (models.load_model)
+                    e.load_optimizer_state(self._pending_opt)
+                    self._pending_opt = None
             e._weights_version = -1
             engines[key] = e
             # least recently used first out -- but never the plan in use, the one holding the freshest weights, or the most
@@ -162,6 +166,7 @@ class PyraPoseModel(object):
         self._loss = loss
         self._optimizer = optimizer or optimizers.Adam(lr=1e-5, clipnorm=0.001)
         self._drop_engines()  # a (re)compiled model starts with fresh optimizer state, like Keras
+        self._pending_opt = None
 
     def get_weights_dict(self):
         return self._engine.params.export() if self._engine is not None else self._weights
@@ -170,9 +175,8 @@ class PyraPoseModel(object):
         """``.npz`` written by save_weights (keys = '<layer>/kernel' HWIO, '<layer>/bias', '<bn>/...').  Keras
         ``.h5`` files need h5py, which this image does not have: convert them with
         ``python -c "import h5py, numpy ..."`` on a machine that does."""
-        with open(filepath, "rb") as f:
-            magic = f.read(8)
-        if magic.startswith(b"\x89HDF"):  # a real Keras / HDF5 file (whatever its name)
+        from ..utils.hdf5_lite import is_hdf5
+        if is_hdf5(filepath):  # a real Keras / HDF5 file (whatever its name; the superblock may sit behind a user block)
             # no h5py / libhdf5 in this image: the subset reader of utils/hdf5_lite.py (version-0 superblock, old-style groups,
             # contiguous datasets -- what Keras 2.3.1 writes) + the Keras -> tensor name mapping.  Written to the HDF5
             # specification, not verified against libhdf5 output: tools/h5_to_npz.py (h5py) is the reference route.
@@ -194,6 +198,8 @@ class PyraPoseModel(object):
             data = np.load(filepath)  # the zip container of save_weights -- also under the '.h5' names of ModelCheckpoint
         W = OrderedDict(self.get_weights_dict())
         for k in data.files:
+            if k.startswith("optimizer/") or k.startswith("config/"):  # a full-model snapshot (save): weights only here
+                continue
             if k not in W:
                 if by_name:
                     continue
@@ -235,7 +241,94 @@ class PyraPoseModel(object):
             if os.path.exists(tmp):
                 os.remove(tmp)
 
-    save = save_weights
+    # ---- full-model snapshots (Keras `model.save`, what bin/train.py:131-142's ModelCheckpoint writes every epoch) ----------
+    def _training_engine(self):
+        return next((o for k, o in reversed(list(self._engines.items())) if k[3]), None)
+
+    def _config(self):
+        cfg = dict(num_classes=self.num_classes, backbone=self.backbone_name, pyramid=self.pyramid, freeze_backbone=bool(self.freeze_backbone))
+        if self._optimizer is not None:
+            o = self._optimizer
+            cfg["optimizer"] = dict(class_name="Adam", config=dict(lr=o.lr, beta_1=o.beta_1, beta_2=o.beta_2, epsilon=o.epsilon, clipnorm=o.clipnorm))
+        if self._loss is not None:
+            cfg["loss"] = {k: dict(kind=l.kind, **{a: getattr(l, a) for a in ("weight", "sigma", "alpha", "gamma") if hasattr(l, a)})
+                           for k, l in self._loss.items()}
+        return cfg
+
+    def optimizer_state(self):
+        """Adam's state (iterations, first / second moments per trainable tensor, Keras layout) or None before the first step"""
+        if self._pending_opt is not None:
+            return self._pending_opt
+        te = self._training_engine()
+        if te is None or te.step_count == 0:
+            return None
+        return te.export_optimizer_state()
+
+    def save(self, filepath, overwrite=True, include_optimizer=True, format=None):
+        """Keras `model.save(filepath)`: weights AND the optimizer's state, so that `models.load_model(filepath)` resumes training
+        where it stopped (bin/train.py:336-343 `--snapshot`).  HDF5 in the layout of keras/engine/saving.py (2.3.1): group
+        'model_weights' (= save_weights), group 'optimizer_weights' with attribute `weight_names` = ['Adam/iterations:0',
+        'training/Adam/m_<i>:0' ..., 'training/Adam/v_<i>:0' ..., 'training/Adam/vhat_<i>:0' ...] (Keras' own order: iterations,
+        first moments, second moments, the (1,)-shaped amsgrad placeholders -- i over the trainable tensors in file order), root
+        attributes `training_config` (optimizer class / config, loss names: Keras' JSON) and `pyrapose_amd_config` (what this
+        package needs to rebuild the model: classes, backbone, pyramid, loss hyper-parameters) plus `pyrapose_amd_optimizer_tensors`
+        (the tensor each m_<i> belongs to, so that loading never depends on an order).  Keras' `model_config` (the JSON of the
+        layer graph) is NOT written -- it cannot be produced without Keras -- so Keras itself can `load_weights` this file but not
+        `load_model` it.  Other extensions / PP_CHECKPOINT_NPZ=1: the numpy container with the same content."""
+        import json
+        if not overwrite and os.path.exists(filepath):
+            raise IOError("save: %s exists" % filepath)
+        if format is None:
+            ext = os.path.splitext(str(filepath))[1].lower()
+            format = "h5" if (ext in (".h5", ".hdf5", ".keras") and os.environ.get("PP_CHECKPOINT_NPZ") != "1") else "npz"
+        state = self.optimizer_state() if include_optimizer else None
+        cfg = self._config()
+        W = self.get_weights_dict()
+        tmp = "%s.tmp.%d" % (filepath, os.getpid())
+        try:
+            if format == "h5":
+                from ..utils import hdf5_lite, keras_names
+                ow, tnames = None, []
+                if state is not None:
+                    tnames = list(state["m"])
+                    ow = OrderedDict([("Adam/iterations:0", np.array(state["iterations"], np.int64))])
+                    for i, n in enumerate(tnames):
+                        ow["training/Adam/m_%d:0" % i] = state["m"][n]
+                    for i, n in enumerate(tnames):
+                        ow["training/Adam/v_%d:0" % i] = state["v"][n]
+                    for i, n in enumerate(tnames):
+                        ow["training/Adam/vhat_%d:0" % i] = np.zeros((1,), np.float32)
+                tc = dict(optimizer_config=cfg.get("optimizer", {}), loss={k: v["kind"] for k, v in cfg.get("loss", {}).items()}, metrics=[],
+                          weighted_metrics=None, sample_weight_mode=None, loss_weights=None)
+                attrs = OrderedDict(training_config=np.bytes_(json.dumps(tc).encode("utf-8")),
+                                    pyrapose_amd_config=np.bytes_(json.dumps(cfg).encode("utf-8")))
+                if tnames:
+                    attrs["pyrapose_amd_optimizer_tensors"] = np.array([n.encode("utf-8") for n in tnames], dtype="S")
+                hdf5_lite.write_keras_model(tmp, keras_names.tensors_to_keras(W), ow, attrs)
+            elif format == "npz":
+                extra = {"config/json": np.frombuffer(json.dumps(cfg).encode("utf-8"), np.uint8)}
+                if state is not None:
+                    extra["optimizer/iterations"] = np.array(state["iterations"], np.int64)
+                    for n in state["m"]:
+                        extra["optimizer/m/" + n] = state["m"][n]
+                        extra["optimizer/v/" + n] = state["v"][n]
+                with open(tmp, "wb") as f:
+                    np.savez(f, **dict(W, **extra))
+            else:
+                raise ValueError("save: format must be 'h5', 'npz' or None, got %r" % (format,))
+            os.replace(tmp, filepath)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+
+    def set_optimizer_state(self, state):
+        """Adam state as optimizer_state() returns it: applied to the training plan (now, or when the first one is built)."""
+        te = self._training_engine()
+        if te is not None:
+            te.load_optimizer_state(state)
+            self._pending_opt = None
+        else:
+            self._pending_opt = state
 
     def predict_on_batch(self, x):
         x = np.ascontiguousarray(x, np.float32)
@@ -319,19 +412,21 @@ class PyraPoseModel(object):
             # produces) runs on rank 0 alone -- N ranks writing the same snapshot path at once would corrupt it; the others wait
             # at the barrier and take rank 0's learning rate and stop flag
             if world > 1:
-                import torch.distributed as dist
-                if rank == 0:
+                from ..parallel import epoch_end_sync
+
+                def rank0_section():
                     for cb in callbacks:
                         if hasattr(cb, "on_epoch_end"):
                             cb.on_epoch_end(epoch, logs)
-                if dist.is_initialized():
-                    state = [float(self.lr or 0.0), bool(self.stop_training)] if rank == 0 else [None, None]
-                    dist.broadcast_object_list(state, src=0)
-                    if rank != 0:
-                        if self._optimizer is not None and state[0] != self.lr:
-                            self.set_lr(state[0])
-                        self.stop_training = state[1]
-                    dist.barrier()
+
+                def take(state):
+                    if self._optimizer is not None and state[0] != self.lr:
+                        self.set_lr(state[0])
+                    self.stop_training = state[1]
+
+                # (gloo side group with a long timeout: an evaluation longer than the RCCL watchdog no longer aborts the job, and
+                # an exception in a rank-0 callback is re-raised on every rank instead of leaving the others in a barrier)
+                epoch_end_sync(rank0_section, lambda: [float(self.lr or 0.0), bool(self.stop_training)], take)
             else:
                 for cb in callbacks:
                     if hasattr(cb, "on_epoch_end"):

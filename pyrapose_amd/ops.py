@@ -36,10 +36,11 @@ class Context:
         self._twin = None
 
     def use_stream(self, stream):
-        self.stream = stream
-        check(lib.pp_ctx_set_stream(self.handle, C.c_void_p(stream.cuda_stream)), self.handle, "pp_ctx_set_stream")
-        if self._twin is not None:
-            self._twin.use_stream(stream)
+        # (the twin points back at this context: bind both handles here instead of forwarding, which would never return)
+        for c in (self, self._twin):
+            if c is not None:
+                c.stream = stream
+                check(lib.pp_ctx_set_stream(c.handle, C.c_void_p(stream.cuda_stream)), c.handle, "pp_ctx_set_stream")
 
     def twin(self, fmt):
         """This context for plane format `fmt` (0 bf16 pairs / bf16x3, 1 P16 / f16c8): itself, or -- created on first use -- a
@@ -205,34 +206,6 @@ def set_grad_scale(ctx, scale2):
     """persistent: the weight gradients of this context divide the gradient scale out (None: gradients are unscaled)"""
     ctx._grad_scale_keep = scale2
     check(lib.pp_ctx_set_grad_scale(ctx.handle, _ptr(scale2)), ctx.handle, "pp_ctx_set_grad_scale")
-
-
-# ---- "f16c8" arithmetic (csrc/conv2.hip): tensors in the H16L8 format, 3 bytes per element ----
-def new_hl(rows, ld, device="cuda"):
-    """A tensor [rows][ld] (ld % 64 == 0) in the H16L8 format: uint8 [rows, ld / 64, 192]."""
-    assert ld % 64 == 0, ld
-    return torch.zeros((rows, ld // 64, 192), dtype=torch.uint8, device=device)
-
-
-def split_hl(ctx, src, dst):
-    rows, ld = src.shape
-    check(lib.pp_split_h16l8(ctx.handle, rows, ld, _ptr(src), _ptr(dst)), ctx.handle, "pp_split_h16l8")
-    return dst
-
-
-def merge_hl(ctx, src, dst):
-    rows, ld = dst.shape
-    check(lib.pp_merge_h16l8(ctx.handle, rows, ld, _ptr(src), _ptr(dst)), ctx.handle, "pp_merge_h16l8")
-    return dst
-
-
-def conv_split_weights2(ctx, d, w, fwd, dgrad):
-    check(lib.pp_conv_split_weights_f16c8(ctx.handle, C.byref(d), _ptr(w), _ptr(fwd), _ptr(dgrad)), ctx.handle, "pp_conv_split_weights_f16c8")
-
-
-def conv_fwd2(ctx, d, x_hl, w_hl, bias, relu, y):
-    check(lib.pp_conv2d_nhwc_fwd_f16c8(ctx.handle, C.byref(d), _ptr(x_hl), _ptr(w_hl), _ptr(bias), int(bool(relu)), _ptr(y)), ctx.handle,
-          "pp_conv2d_nhwc_fwd_f16c8")
 
 
 def _set_capture(ctx, planes):

@@ -40,6 +40,55 @@ def ensure_process_group(device=None):
     return world
 
 
+_CONTROL_GROUP = None
+
+
+def control_group():
+    """A gloo side group for host-side, long-wait synchronisation (the epoch end of fit_generator: rank 0 snapshots and evaluates,
+    possibly for longer than the RCCL watchdog's 10 minutes, while the other ranks wait).  Created on first use -- collectively,
+    every rank must call this at the same point -- with a timeout of PP_EPOCH_END_TIMEOUT_S seconds (default 24 h)."""
+    global _CONTROL_GROUP
+    if not dist.is_initialized():
+        return None
+    if _CONTROL_GROUP is None:
+        import datetime
+        secs = float(os.environ.get("PP_EPOCH_END_TIMEOUT_S", "86400"))
+        _CONTROL_GROUP = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=secs))
+    return _CONTROL_GROUP
+
+
+class RankZeroFailed(RuntimeError):
+    """raised on every rank when the rank-0 section of epoch_end_sync raised (the original traceback text is the message)"""
+
+
+def epoch_end_sync(rank0_fn, get_state, set_state):
+    """Run `rank0_fn()` on rank 0 only, then hand `get_state()` of rank 0 to `set_state(state)` on the other ranks.  The wait is a
+    broadcast on the gloo control group (no RCCL collective is pending meanwhile, so no watchdog can fire however long rank 0
+    works), and an exception in rank0_fn travels with the state: EVERY rank raises (rank 0 the original exception, the others
+    RankZeroFailed with its traceback), so the job exits non-zero together instead of N - 1 ranks hanging in a barrier."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        rank0_fn()
+        return
+    grp = control_group()
+    rank = dist.get_rank()
+    err, exc, state = None, None, None
+    if rank == 0:
+        try:
+            rank0_fn()
+            state = get_state()
+        except BaseException as e:  # noqa: BLE001 -- the failure is re-raised below, after the others have been told
+            import traceback
+            exc, err = e, traceback.format_exc()
+    box = [state, err]
+    dist.broadcast_object_list(box, src=0, group=grp)
+    if box[1] is not None:
+        if rank == 0:
+            raise exc
+        raise RankZeroFailed("rank 0 failed in its epoch-end section:\n%s" % box[1])
+    if rank != 0:
+        set_state(box[0])
+
+
 def bucket_bytes_from_env(default=32 << 20):
     """PP_BUCKET_MB: size at which the flat gradient buffer is cut into all-reduce buckets (default 32 MB: ~6 buckets for the
     169 MB of ResNet-50 gradients; xGMI is point to point, so fewer, larger collectives beat many small ones)."""

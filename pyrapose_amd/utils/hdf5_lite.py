@@ -61,6 +61,19 @@ def find_superblock(data):
     return -1
 
 
+def is_hdf5(path):
+    """True when `path` holds an HDF5 superblock at one of the offsets find_superblock() accepts (only those bytes are read)."""
+    with open(path, "rb") as f:
+        size = f.seek(0, 2)
+        off = 0
+        while off + 8 <= size:
+            f.seek(off)
+            if f.read(8) == SIGNATURE:
+                return True
+            off = 512 if off == 0 else off * 2
+    return False
+
+
 class _Reader(object):
     def __init__(self, data):
         self.b = data
@@ -529,28 +542,28 @@ def _write_group(w, children, attrs):
     return _header(w, msgs), btree, heap
 
 
-def write_keras_weights(path, layers, root_attrs=None):
-    """Write {layer_group: {weight_name: array}} in the layout of Keras-2.3.1 `save_weights` (layer_names / weight_names
-    attributes, nested groups for the '/' of weight names, contiguous float32 datasets)."""
-    def insert(tree, parts, arr):
-        if len(parts) == 1:
-            tree[parts[0]] = ("data", np.asarray(arr))
-        else:
-            node = tree.setdefault(parts[0], ("group", OrderedDict(), OrderedDict()))
-            insert(node[1], parts[1:], arr)
-    root = OrderedDict()
-    most = max([len(layers)] + [1])
-    for lname, ws in layers.items():
-        sub = OrderedDict()
-        for wname, arr in ws.items():
-            insert(sub, wname.split("/"), arr)
-        wn = np.array([n.encode("utf-8") for n in ws], dtype="S") if ws else np.zeros((0,), "S1")
-        root[lname] = ("group", sub, OrderedDict(weight_names=wn))
-    attrs = OrderedDict(layer_names=np.array([n.encode("utf-8") for n in layers], dtype="S"), backend=np.bytes_(b"tensorflow"),
-                        keras_version=np.bytes_(b"2.3.1"))
-    attrs.update(root_attrs or {})
-    w = _Writer(leaf_k=max(4, (most + 1) // 2))
-    hdr, bt, hp = _write_group(w, root, attrs)
+def _tree_insert(tree, parts, arr):
+    if len(parts) == 1:
+        tree[parts[0]] = ("data", np.asarray(arr))
+    else:
+        node = tree.setdefault(parts[0], ("group", OrderedDict(), OrderedDict()))
+        _tree_insert(node[1], parts[1:], arr)
+
+
+def _largest_group(children):
+    n = len(children)
+    for c in children.values():
+        if c[0] == "group":
+            n = max(n, _largest_group(c[1]))
+    return n
+
+
+def write_tree(path, children, attrs):
+    """children: {name: ('group', children, attrs) | ('data', array)}, attrs: root attributes -> one HDF5 file (version-0
+    superblock, old-style groups with ONE symbol-table node each: the group leaf K of the superblock is sized for the largest
+    group of the tree)."""
+    w = _Writer(leaf_k=max(4, (_largest_group(children) + 1) // 2))
+    hdr, bt, hp = _write_group(w, children, attrs)
     eof = len(w.buf)
     sb = SIGNATURE + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, w.leaf_k, 16, 0) + struct.pack("<QQQQ", 0, UNDEF, eof, UNDEF)
     sb += struct.pack("<QQII", 0, hdr, 1, 0) + struct.pack("<QQ", bt, hp)
@@ -558,3 +571,59 @@ def write_keras_weights(path, layers, root_attrs=None):
     w.put(0, sb)
     with open(path, "wb") as f:
         f.write(bytes(w.buf))
+
+
+def _weights_group(layers):
+    """{layer_group: {weight_name: array}} -> (children, attrs) of a Keras 'model_weights' group (= the root of a save_weights file)"""
+    root = OrderedDict()
+    for lname, ws in layers.items():
+        sub = OrderedDict()
+        for wname, arr in ws.items():
+            _tree_insert(sub, wname.split("/"), arr)
+        wn = np.array([n.encode("utf-8") for n in ws], dtype="S") if ws else np.zeros((0,), "S1")
+        root[lname] = ("group", sub, OrderedDict(weight_names=wn))
+    attrs = OrderedDict(layer_names=np.array([n.encode("utf-8") for n in layers], dtype="S"), backend=np.bytes_(b"tensorflow"),
+                        keras_version=np.bytes_(b"2.3.1"))
+    return root, attrs
+
+
+def write_keras_weights(path, layers, root_attrs=None):
+    """Write {layer_group: {weight_name: array}} in the layout of Keras-2.3.1 `save_weights` (layer_names / weight_names
+    attributes, nested groups for the '/' of weight names, contiguous float32 datasets)."""
+    root, attrs = _weights_group(layers)
+    attrs.update(root_attrs or {})
+    write_tree(path, root, attrs)
+
+
+def write_keras_model(path, layers, optimizer_weights=None, root_attrs=None):
+    """The layout of Keras-2.3.1 `model.save` (keras/engine/saving.py _serialize_model): root attributes (keras_version, backend,
+    training_config, ... = root_attrs), group 'model_weights' (as write_keras_weights) and -- optimizer_weights: OrderedDict
+    {weight name: array} in the optimizer's own order -- group 'optimizer_weights' with the attribute `weight_names` and one
+    dataset per name ('/' nests groups)."""
+    mw, mw_attrs = _weights_group(layers)
+    root = OrderedDict(model_weights=("group", mw, mw_attrs))
+    if optimizer_weights:
+        ow = OrderedDict()
+        for n, arr in optimizer_weights.items():
+            _tree_insert(ow, n.split("/"), arr)
+        root["optimizer_weights"] = ("group", ow, OrderedDict(weight_names=np.array([n.encode("utf-8") for n in optimizer_weights], dtype="S")))
+    attrs = OrderedDict(backend=np.bytes_(b"tensorflow"), keras_version=np.bytes_(b"2.3.1"))
+    attrs.update(root_attrs or {})
+    write_tree(path, root, attrs)
+
+
+def read_optimizer_weights(path):
+    """-> (OrderedDict {weight name: array} in file order or None when the file has no 'optimizer_weights' group, root attributes)"""
+    f = File(path)
+    if "optimizer_weights" not in f:
+        return None, f.attrs
+    g = f["optimizer_weights"]
+    if "weight_names" in g.attrs:
+        vals = list(np.atleast_1d(g.attrs["weight_names"]))
+    else:
+        vals, i = [], 0
+        while "weight_names%d" % i in g.attrs:
+            vals.extend(np.atleast_1d(g.attrs["weight_names%d" % i]))
+            i += 1
+    names = [v.decode("utf-8") if isinstance(v, (bytes, np.bytes_)) else str(v) for v in vals]
+    return OrderedDict((n, g[n].read()) for n in names), f.attrs

@@ -86,3 +86,16 @@ def tensors_to_keras(W, first_auto_index=1, reg_model="model_1", cls_model="mode
             v = inv_bn.get(var, var)
             layers.setdefault(layer, OrderedDict())["%s/%s:0" % (layer, v)] = np.asarray(arr)
     return layers
+
+
+def trainable_tensor_order(model):
+    """'<layer>/kernel', '<layer>/bias' of the tensors Adam updates, in this package's graph order (= the order in which
+    PyraPoseModel.save numbers Keras' m_<i> / v_<i>): conv1 / res2 and every BatchNormalization are frozen (models/resnet.py:87-103)."""
+    from .. import arch
+    out = []
+    for s in arch.all_specs(model.num_classes, model.backbone_name, model.pyramid, model.anchor_params.num_anchors()):
+        if s.trainable and not (model.freeze_backbone and s.bn):
+            out.append(s.name + "/kernel")
+            if s.bias:
+                out.append(s.name + "/bias")
+    return out

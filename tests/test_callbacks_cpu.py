@@ -24,11 +24,63 @@ def test_model_checkpoint_redirect_and_reload(tmp_path):
         with open(os.path.join(str(tmp_path), f), "rb") as fh:
             assert fh.read(8) == b"\x89HDF\r\n\x1a\n"
     from pyrapose_amd.utils import hdf5_lite
-    assert "layer_names" in hdf5_lite.File(os.path.join(str(tmp_path), files[0])).attrs
+    f0 = hdf5_lite.File(os.path.join(str(tmp_path), files[0]))  # Keras' model.save layout: the weights sit in 'model_weights'
+    assert "layer_names" in f0["model_weights"].attrs and "training_config" in f0.attrs
+    wo = callbacks.ModelCheckpoint(os.path.join(str(tmp_path), "w.h5"), save_weights_only=True)
+    wo.set_model(model)
+    wo.on_epoch_end(0, {})
+    assert "layer_names" in hdf5_lite.File(os.path.join(str(tmp_path), "w.h5")).attrs  # save_weights layout: at the root
+    os.remove(os.path.join(str(tmp_path), "w.h5"))
     loaded = models.load_model(os.path.join(str(tmp_path), files[1]), backbone_name="resnet50")
     w0, w1 = model.get_weights_dict(), loaded.get_weights_dict()
     assert set(w0) == set(w1) and all(np.array_equal(w0[k], w1[k]) for k in w0)
     assert w0["reg_conv0/kernel"].shape == (3, 3, 256, 512)  # Keras HWIO
+
+
+@pytest.mark.parametrize("name", ["full.h5", "full.npz"])
+def test_full_model_snapshot_round_trips_optimizer_state_and_compile_state(tmp_path, name):
+    """`model.save` carries Adam's iterations / m / v and the compile state; `models.load_model` restores
+    them (bin/train.py:131-142 writes full models, :336-343 resumes from them).  No GPU: the state waits for the first training plan."""
+    import json
+    from pyrapose_amd import losses
+    from pyrapose_amd.utils import hdf5_lite, keras_names
+    model = models.backbone("resnet50").retinanet(num_classes=3)
+    model.compile(loss={"3Dbox": losses.orthogonal_l1(weight=0.25, sigma=2.0), "cls": losses.focal(alpha=0.3), "mask": losses.focal(gamma=1.5)},
+                  optimizer=optimizers.Adam(lr=3e-5, clipnorm=0.01, beta_2=0.99))
+    assert model.optimizer_state() is None
+    order = keras_names.trainable_tensor_order(model)
+    assert order[0] == "res3a_branch2a/kernel" and "conv1/kernel" not in order and "reg_out/bias" in order and "res3a_branch2a/bias" not in order
+    W = model.get_weights_dict()
+    rng = np.random.default_rng(0)
+    state = dict(iterations=1234, m={k: rng.standard_normal(W[k].shape).astype(np.float32) for k in order},
+                 v={k: rng.random(W[k].shape).astype(np.float32) for k in order})
+    model.set_optimizer_state(state)
+    path = os.path.join(str(tmp_path), name)
+    model.save(path)
+    if name.endswith(".h5"):
+        ow, attrs = hdf5_lite.read_optimizer_weights(path)
+        names = list(ow)
+        n = len(order)
+        assert names[0] == "Adam/iterations:0" and ow[names[0]].dtype == np.int64 and int(ow[names[0]]) == 1234
+        assert names[1] == "training/Adam/m_0:0" and names[1 + n] == "training/Adam/v_0:0" and names[1 + 2 * n] == "training/Adam/vhat_0:0"
+        assert len(names) == 1 + 3 * n and ow[names[-1]].shape == (1,)
+        tc = json.loads(bytes(attrs["training_config"]).decode())
+        assert tc["optimizer_config"]["class_name"] == "Adam" and tc["optimizer_config"]["config"]["clipnorm"] == 0.01
+        assert tc["loss"] == {"3Dbox": "orthogonal_l1", "cls": "focal", "mask": "focal"}
+    back = models.load_model(path, backbone_name="resnet50")
+    assert back.num_classes == 3 and back._optimizer.lr == 3e-5 and back._optimizer.beta_2 == 0.99 and back._optimizer.clipnorm == 0.01
+    assert back._loss["3Dbox"].weight == 0.25 and back._loss["3Dbox"].sigma == 2.0 and back._loss["cls"].alpha == 0.3 and back._loss["mask"].gamma == 1.5
+    got = back.optimizer_state()
+    assert got["iterations"] == 1234 and list(got["m"]) == order
+    assert all(np.array_equal(got["m"][k], state["m"][k]) and np.array_equal(got["v"][k], state["v"][k]) for k in order)
+    w1 = back.get_weights_dict()
+    assert all(np.array_equal(W[k], w1[k]) for k in W)
+    # weights-only loading of a full snapshot ignores the optimizer part; recompiling drops the restored state, like Keras
+    m2 = models.backbone("resnet50").retinanet(num_classes=3)
+    m2.load_weights(path)
+    assert np.array_equal(m2.get_weights_dict()["P5/kernel"], W["P5/kernel"]) and m2.optimizer_state() is None
+    back.compile(loss=back._loss, optimizer=optimizers.Adam(lr=1e-5, clipnorm=0.001))
+    assert back.optimizer_state() is None
 
 
 def test_checkpoint_container_escape_and_formats(tmp_path, monkeypatch):

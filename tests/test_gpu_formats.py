@@ -60,6 +60,29 @@ def test_convert_planes_round_trip_scale_and_mask(ctx):
         ops.convert_planes(ctx, p0, 0, out, 2)
 
 
+def test_use_stream_on_twinned_context_rebinds_both(ctx):
+    """Context.use_stream used to forward to the twin, which forwarded back (RecursionError in the default mixed mode,
+    where every engine context has a twin).  Both handles must move, and launches of either format must run on the new stream."""
+    from pyrapose_amd import ops
+    c = ops.Context(0)
+    t = c.twin(1)
+    assert t.twin(0) is c
+    side = torch.cuda.Stream()
+    c.use_stream(side)
+    assert c.stream is side and t.stream is side
+    x = torch.randn((64, 32), device="cuda")
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for cc, fmt in ((c, 0), (t, 1)):
+            p = ops.new_planes(64, 32)
+            ops.split_planes3(cc, x, p[0], p[1])
+            assert float((ops.planes_to_f32(p, fmt) - x).abs().max()) <= 2.0 ** -14 * float(x.abs().max())
+    t.use_stream(torch.cuda.current_stream())  # from the twin's side too
+    assert c.stream is t.stream
+    torch.cuda.synchronize()
+    c.close()
+
+
 def test_p16_range(ctx):
     """|x| is clamped to 28672 (the remainder * 2^12 must fit e5m2); what a half cannot hold at all (< 2^-24) becomes zero -- the
     reason gradients travel scaled."""

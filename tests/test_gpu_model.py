@@ -65,7 +65,7 @@ def test_known_answers_initial_outputs(ctx):
     np.testing.assert_allclose(mask.cpu().numpy(), 0.01, rtol=1e-5)
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "mixed"])
 @pytest.mark.parametrize("shape", [(2, 64, 96, 13), (1, 97, 131, 5)])
 def test_forward_small_vs_oracle_f64(ctx, shape, mode):
     from oracle import anchors_np as OA
@@ -223,7 +223,7 @@ def test_adam_clipnorm_kernel_vs_oracle(ctx):
         opt.close()
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "mixed"])
 def test_forward_full_size_vs_oracle(ctx, mode):
     """BASELINE configs[0]: single 640x480 image, ResNet-50 PFPN inference, C=13."""
     from oracle import model_torch as MT

@@ -221,3 +221,48 @@ def test_optimizer_state_survives_prediction_at_another_batch_size(ctx):
     tg1 = [t[:1] for t in tg]
     model.train_on_batch(x4, tg1)
     assert model._engine is not eng and model._engine.train and model._engine.step_count == 4
+
+
+@pytest.mark.parametrize("name", ["snap_01.h5", "snap_01.npz"])
+def test_full_model_snapshot_resumes_training_with_the_optimizer_state(ctx, tmp_path, name):
+    """VERDICT r03 item 5 (f1; bin/train.py:131-142 + :336-343): 2 steps -> model.save -> a FRESH model from models.load_model ->
+    1 step  ==  3 uninterrupted steps (Adam's m, v and iteration count travel in the snapshot; a weights-only resume restarts the
+    bias correction and lands elsewhere)."""
+    import os
+    from pyrapose_amd import losses, models, optimizers
+    B, H, W, C = 2, 64, 96, 5
+    rng = np.random.default_rng(61)
+    x = synth_input(rng, B, H, W)
+    N = sum(-(-H // 2 ** l) * -(-W // 2 ** l) for l in (3, 4, 5)) * 9
+    M3 = -(-H // 8) * -(-W // 8)
+    tg = random_targets(rng, B, N, M3, C, pos_frac=0.05)
+
+    def fresh():
+        m = models.backbone("resnet50").retinanet(C)
+        m.compile(loss={"3Dbox": losses.orthogonal_l1(), "cls": losses.focal(), "mask": losses.focal()},
+                  optimizer=optimizers.Adam(lr=1e-4, clipnorm=0.001))
+        return m
+    a = fresh()
+    for _ in range(2):
+        a.train_on_batch(x, list(tg))
+    path = os.path.join(str(tmp_path), name)
+    a.save(path)
+    w2 = a._engine.params.w_master.clone()
+    a._drop_engines()
+    del a
+    b = models.load_model(path, backbone_name="resnet50")  # compile state comes with the file: no compile() here
+    assert b.optimizer_state()["iterations"] == 2
+    b.train_on_batch(x, list(tg))
+    assert b._engine.step_count == 3
+    ref = fresh()
+    for _ in range(3):
+        ref.train_on_batch(x, list(tg))
+    w3, w3_ref = b._engine.params.w_master, ref._engine.params.w_master
+    assert float((w3 - w3_ref).abs().max()) <= 1e-6 * float(w3_ref.abs().max()) + 1e-9
+    assert float((b._engine.params.m - ref._engine.params.m).abs().max()) <= 1e-6 * float(ref._engine.params.m.abs().max()) + 1e-12
+    # the control: the same file loaded weights-only restarts Adam (step 1 of a fresh optimizer is a full-size sign step)
+    c = fresh()
+    c.load_weights(path)
+    c.train_on_batch(x, list(tg))
+    assert float((c._engine.params.w_master - w3_ref).abs().max()) > 10 * float((w3 - w3_ref).abs().max()) + 1e-7
+    assert float((w3_ref - w2).abs().max()) > 0

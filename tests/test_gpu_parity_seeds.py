@@ -1,6 +1,6 @@
 """GPU: the full-size parity of the default (mixed-arithmetic) training step over SEVERAL seeds of weights, images and annotations.
 Round 3 moved FPN + heads to the f16c8 arithmetic, which took the margin under the 1e-3 bar from ~10x to ~3.5x; one seed is not
-evidence at that distance.  Default: one more seed of BASELINE configs[1] beside tests/test_gpu_parity.py's; PP_PARITY_SEEDS=n runs
+evidence at that distance.  Default: three more seeds of BASELINE configs[1] beside tests/test_gpu_parity.py's; PP_PARITY_SEEDS=n runs
 n (the round's sweep of 8 is profiles/r03_parity_seed_sweep.txt).  Run with -s for the margins."""
 import os
 
@@ -10,7 +10,7 @@ from tests.test_gpu_parity import _train_step_vs_oracle
 
 pytestmark = pytest.mark.gpu
 
-N_SEEDS = int(os.environ.get("PP_PARITY_SEEDS", "1"))
+N_SEEDS = int(os.environ.get("PP_PARITY_SEEDS", "3"))
 
 
 @pytest.fixture(scope="module")

@@ -163,3 +163,86 @@ def test_two_rank_allreduce_matches_single_process():
         assert np.array_equal(c, np.array([7, 15, 1, 0], np.int32))
         np.testing.assert_allclose(g, want, rtol=1e-6, atol=1e-6)
     assert np.array_equal(res[0][1], res[1][1])   # both ranks hold the identical reduced buffer
+
+
+def _sync_worker(rank, world, port, fail, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["PP_EPOCH_END_TIMEOUT_S"] = "120"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pyrapose_amd import parallel
+    box = {"lr": 1e-5, "stop": False, "ran": 0}
+
+    def rank0():
+        box["ran"] += 1
+        if fail:
+            raise ValueError("snapshot disk full")
+        box["lr"], box["stop"] = 2.5e-6, True
+
+    try:
+        parallel.epoch_end_sync(rank0, lambda: [box["lr"], box["stop"]], lambda s: box.update(lr=s[0], stop=s[1]))
+        q.put((rank, "ok", box["lr"], box["stop"], box["ran"]))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, type(e).__name__, str(e)[-200:], None, box["ran"]))
+        dist.destroy_process_group()
+        raise SystemExit(3)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail", [False, True])
+def test_epoch_end_sync_state_and_failure_reach_every_rank(fail):
+    """rank 0 alone runs the epoch-end callbacks; its learning rate / stop flag reach the other rank over the gloo
+    control group, and when a rank-0 callback raises EVERY rank raises and exits non-zero (no rank is left in a barrier)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, fail, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r = q.get(timeout=120)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == (3 if fail else 0)
+    assert res[0][3] == 1 and res[1][3] == 0          # the section ran on rank 0 only
+    if fail:
+        assert res[0][0] == "ValueError" and res[1][0] == "RankZeroFailed" and "snapshot disk full" in res[1][1]
+    else:
+        assert res[0][:3] == ("ok", 2.5e-6, True) and res[1][:3] == ("ok", 2.5e-6, True)
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_bucket_plan_and_batch_dealing_at_world_4_and_8(world):
+    """the bucket plan does not depend on the world size and covers every trainable float exactly once with
+    monotone release indices; fit_generator's dealing (rank r takes batches r, r + world, ...) visits every batch of an epoch once."""
+    from pyrapose_amd.parallel import plan_buckets
+    rng = np.random.default_rng(world)
+    sizes = [int(v) for v in rng.integers(64, 400000, size=40)]
+    frozen = set(range(6))
+    entries, total = make_layout(sizes, frozen)
+    names = list(entries)
+    ops = []
+    for n in reversed(names[6:]):
+        e = entries[n]
+        ops += [FakeOp(None), FakeOp((e["offset"], e["offset"] + e["count"]))]
+    for mb in (1, 4, 32):
+        buckets = plan_buckets(entries, ops, bucket_bytes=mb << 20)
+        cover = np.zeros(total, np.int32)
+        for a, b, _ in buckets:
+            cover[a:b] += 1
+        for i, n in enumerate(names):
+            e = entries[n]
+            want = 0 if i in frozen else 1
+            assert (cover[e["offset"]: e["offset"] + e["count"]] == want).all(), (n, mb)
+        rel = [r for _, _, r in buckets]
+        assert rel == sorted(rel) and rel[0] >= 0
+    # dealing: `steps` global steps of `world` batches; the generator has n_batches batches
+    n_batches = 8 * world + 3
+    steps = -(-n_batches // world)
+    seen = []
+    for rank in range(world):
+        seen += [(i * world + rank) % n_batches for i in range(steps)]
+    assert set(seen) == set(range(n_batches))                      # every batch of the epoch is visited
+    assert len(seen) - n_batches < world                           # at most one partial global step wraps around

@@ -1,4 +1,4 @@
-// Building blocks of the "f16c8" convolution arithmetic (conv2.hip), checked on the hardware before the kernel relies on them:
+// Building blocks of the "f16c8" convolution arithmetic (csrc/planes_fmt.h, PP_FMT == 1), checked on the hardware before the kernel relies on them:
 //   x = x_hi + x_lo, x_hi = f16(x), x_lo8 = e5m2(x_lo * 2^12); the same for w
 //   x*w ~= x_hi*w_hi (v_mfma_f32_32x32x16_f16) + [x_hi8*w_lo8 + x_lo8*w_hi8] * 2^-12 (v_mfma_scale_f32_32x32x64_f8f6f4, e5m2
 //   operands, E8M0 scale 2^-12 on the "lo" side), x_hi8 = the top byte of x_hi (e5m2 IS the top byte of an IEEE half).
