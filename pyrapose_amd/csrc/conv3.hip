@@ -21,6 +21,7 @@
 // [4 k-octets][rows][8 x 16 bit], rows of octet o rotated by 2*o so that both the 16-byte stores of the staging
 // threads (4 threads per row) and the 512-byte fragment reads are bank-conflict free.
 #include "conv_common.h"
+#include "conv4.h"
 
 // Everything below is compiled once per plane format (PP_FMT = 0: bf16 pairs / bf16x3, PP_FMT = 1: P16 / f16c8; planes_fmt.h) with
 // internal linkage; the entry points carry the format in their name and conv3_dispatch.hip forwards pp_* to the build the
@@ -35,225 +36,7 @@
 namespace {
 #include "planes_fmt.h"
 
-__device__ __forceinline__ void split8(const float4& lo4, const float4& hi4, uint4* out_hi, uint4* out_lo) {
-  fmt_encode2(lo4.x, lo4.y, &out_hi->x, &out_lo->x);
-  fmt_encode2(lo4.z, lo4.w, &out_hi->y, &out_lo->y);
-  fmt_encode2(hi4.x, hi4.y, &out_hi->z, &out_lo->z);
-  fmt_encode2(hi4.z, hi4.w, &out_hi->w, &out_lo->w);
-}
-
-// AP: the gathered operand comes from pre-split (hi, lo) planes (pp_split_planes_bf16x3, same [rows][ld]
-// geometry as the f32 tensor) instead of being split from f32 while staging: no conversion VALU in the loop.
-__device__ __forceinline__ void split4(const float4& v4, uint2* out_hi, uint2* out_lo) {
-  fmt_encode2(v4.x, v4.y, &out_hi->x, &out_lo->x);
-  fmt_encode2(v4.z, v4.w, &out_hi->y, &out_lo->y);
-}
-
-// ---- the PACKED plane layout ----
-// A tensor [rows][ld] (ld % 8 == 0) stored as (hi, lo) planes occupies rows * ld * 4 bytes, like float32, cut into 32-byte
-// groups of 8 consecutive channels: bytes 0..15 = the 8 hi halves, bytes 16..31 = the 8 lo units (value = hi + lo8 * 2^-12, within
-// 2^-15 of the float32 that was split).  "hi" points at the buffer, "lo" 16 bytes behind it, and BOTH are addressed with the
-// float32 byte offsets of the element's group -- so a staging thread that used to fetch the two float4 of an octet fetches
-// the same 32 contiguous bytes, and 128-byte row segments stay whole (two separate planes cut every access into 64-byte
-// halves and cost 5 % on the forward launches: profiles/r02_planes_separate_vs_packed.txt).
-// index of the 8-byte half-group (4 channels) i4 = element / 4 of a plane, in uint2 units from the plane's pointer
-__device__ __forceinline__ long long pk4(long long i4) { return ((i4 >> 1) << 2) + (i4 & 1); }
-
-// four consecutive elements (element index 4 * i4) of a tensor stored as planes
-__device__ __forceinline__ float4 planes_ld4(const void* hi, const void* lo, long long i4) {
-  const long long q = pk4(i4);
-  const uint2 h = reinterpret_cast<const uint2*>(hi)[q], l = reinterpret_cast<const uint2*>(lo)[q];
-  float4 v;
-  fmt_value2(h.x, l.x, &v.x, &v.y);
-  fmt_value2(h.y, l.y, &v.z, &v.w);
-  return v;
-}
-// the hi plane alone: enough for the sign / zero test of a ReLU source (+1 / 0 per element)
-__device__ __forceinline__ float4 hi_ld4(const void* hi, long long i4) {
-  const uint2 h = reinterpret_cast<const uint2*>(hi)[pk4(i4)];
-  return make_float4(fmt_pos(h.x & 0xffffu) ? 1.f : 0.f, fmt_pos(h.x >> 16) ? 1.f : 0.f, fmt_pos(h.y & 0xffffu) ? 1.f : 0.f,
-                     fmt_pos(h.y >> 16) ? 1.f : 0.f);
-}
-__device__ __forceinline__ void planes_st4(void* hi, void* lo, long long i4, const float4& v) {
-  uint2 oh, ol;
-  split4(v, &oh, &ol);
-  const long long q = pk4(i4);
-  reinterpret_cast<uint2*>(hi)[q] = oh;
-  reinterpret_cast<uint2*>(lo)[q] = ol;
-}
-
-// exchange with the neighbouring lane (lane ^ 1) inside a quad: DPP quad_perm [1, 0, 3, 2]
-__device__ __forceinline__ unsigned lane_xor1(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }
-
-// exact a / b for 0 <= a < 2^24, b >= 1 by one reciprocal multiply and a +-1 correction
-__device__ __forceinline__ int div_small(int a, int b, float rcp_b, int* rem) {
-  int q = (int)((float)a * rcp_b);
-  int r = a - q * b;
-  const bool lo = r < 0;
-  q -= lo ? 1 : 0;
-  r += lo ? b : 0;
-  const bool hi = r >= b;
-  q += hi ? 1 : 0;
-  r -= hi ? b : 0;
-  *rem = r;
-  return q;
-}
-
-// ---- epilogue through LDS (see conv.hip), shared by both main loops ----
-// (Measured and not kept: non-temporal stores for the output tile -- the next launch reads it back, and the step lost 1 %.)
-// RL: the tile's BM rows are BM / 32 listed 32-row blocks (rl_blk[j] = first row of block j of this tile, >= M when the
-// list has ended) instead of the consecutive rows m0 ..
-template <int TM, int TN, bool OP, int GOP = 1, bool SC = false, bool XR = false, bool RL = false, int NWM = 2, int NT = 256>
-__device__ __forceinline__ void epilogue3(const IgemmParams& p, floatx16 (&acc)[TM][TN], uint4* smem, int m0, int n0, int tid, int wm,
-                                          int wn, int il, int h, const float* __restrict__ g_bias,
-                                          const float* __restrict__ g_addend, const float* __restrict__ g_mask,
-                                          float* __restrict__ g_out, uint2* __restrict__ g_ohi, uint2* __restrict__ g_olo,
-                                          const int* rl_blk = nullptr) {
-  constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, NO = BK / 8;
-  constexpr int SMEM_U4 = 2 * NO * (BM + BN);
-  // blocked sub-tiles here, so staged row = (a - a0) * 32 + i
-  constexpr int SUB = (TM == 4) ? 2 : ((TM * BN > 256 * 1) ? 1 : TM);  // 32*SUB rows x BN floats must fit the LDS buffer
-  constexpr int ROWS = 32 * SUB;
-  constexpr int C4 = BN / 4;
-  constexpr int RPI = NT / C4;
-  constexpr int SWEEPS = ROWS / RPI;
-  static_assert(ROWS * BN * 4 <= SMEM_U4 * 16, "epilogue staging does not fit");
-  static_assert(SWEEPS >= 1 && ROWS % RPI == 0, "epilogue sweep geometry");
-  float* stage = reinterpret_cast<float*>(smem);
-  const int e_c4 = tid % C4, e_r = tid / C4;
-  const int co = n0 + 4 * e_c4;
-  const bool odd = (e_c4 & 1) != 0;  // lanes 2j / 2j + 1 hold channels 8j .. 8j+3 / 8j+4 .. 8j+7 of the same row
-  const bool col_ok = co < ((p.Nout + 3) & ~3);
-  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (g_bias && col_ok) bias4 = *reinterpret_cast<const float4*>(g_bias + co);
-  const int m_last = p.M - 1;
-  const bool add_pl = p.add_hi != nullptr, mask_pl = p.mask_hi != nullptr;  // (uniform) operands stored as bf16 planes
-#pragma unroll
-  for (int hm = 0; hm < NWM; ++hm) {
-#pragma unroll
-    for (int a0 = 0; a0 < TM; a0 += SUB) {
-      __syncthreads();
-      if (wm == hm) {
-#pragma unroll
-        for (int as = 0; as < SUB; ++as)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = as * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-#pragma unroll
-            for (int b = 0; b < TN; ++b) stage[row * BN + wn * 32 * TN + b * 32 + il] = acc[a0 + as][b][r];
-          }
-      }
-      __syncthreads();
-      if (col_ok) {
-        constexpr int G = OP ? (SWEEPS < GOP ? SWEEPS : GOP) : (SWEEPS < 4 ? SWEEPS : 4);  // rows in flight per thread
-        const int base_row = m0 + hm * 32 * TM + a0 * 32;
-        auto sweep = [&](auto has_add, auto has_mask) {
-#pragma unroll
-          for (int s0 = 0; s0 < SWEEPS; s0 += G) {
-            float4 ad[G], mk[G];
-            int mo[G];  // row of the output / addend / mask tensors (SC: the class row scattered into the full grid)
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-              int m = XR ? max(min(base_row + e_r + RPI * (s0 + g), m_last), 0) : min(base_row + e_r + RPI * (s0 + g), m_last);
-              if (RL) {
-                const int t = hm * 32 * TM + a0 * 32 + e_r + RPI * (s0 + g);
-                m = min(rl_blk[t >> 5] + (t & 31), m_last);
-              }
-              mo[g] = m;
-              if (SC) {
-                const int hw = p.seg[0].OH * p.seg[0].OW;
-                int rem, xq;
-                const int n = div_small(m, hw, __frcp_rn((float)hw), &rem);
-                const int yq = div_small(rem, p.seg[0].OW, __frcp_rn((float)p.seg[0].OW), &xq);
-                mo[g] = (n * p.sc_H + 2 * yq + p.sc_cy) * p.sc_W + 2 * xq + p.sc_cx;
-              }
-              if (has_add) {
-                if (add_pl) {
-                  // packed planes, 16 bytes per lane: the even lane of a pair fetches the group's hi half, the odd lane its lo half
-                  // (8-byte loads run at 0.5-0.7 of the 16-byte rate: the HBM-bound 1x1 launches were 6-25 % slower with them)
-                  const long long grp = ((long long)mo[g] * p.ld_add + (co & ~7)) >> 3;
-                  const uint4 q = reinterpret_cast<const uint4*>(p.add_hi)[2 * grp + (odd ? 1 : 0)];
-                  ad[g] = *reinterpret_cast<const float4*>(&q);  // raw halves: combined after the exchange below
-                } else {
-                  ad[g] = *reinterpret_cast<const float4*>(g_addend + (long long)mo[g] * p.ld_add + co);
-                }
-              }
-              if (has_mask) {
-                if (mask_pl) {
-                  // the hi half of the group alone (hi > 0 <=> value > 0): the even lane fetches it for the pair
-                  const long long grp = ((long long)mo[g] * p.ld_mask + (co & ~7)) >> 3;
-                  uint4 q = make_uint4(0u, 0u, 0u, 0u);
-                  if (!odd) q = reinterpret_cast<const uint4*>(p.mask_hi)[2 * grp];
-                  mk[g] = *reinterpret_cast<const float4*>(&q);
-                } else {
-                  mk[g] = *reinterpret_cast<const float4*>(g_mask + (long long)mo[g] * p.ld_mask + co);
-                }
-              }
-            }
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-              const int row = e_r + RPI * (s0 + g);
-              int m = base_row + row;
-              if (RL) {
-                const int t = hm * 32 * TM + a0 * 32 + row;
-                m = rl_blk[t >> 5] + (t & 31);
-              }
-              float4 v = *reinterpret_cast<const float4*>(stage + row * BN + 4 * e_c4);
-              v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-              if (has_add && add_pl) {
-                // even lane holds hi[0..7], odd lane lo[0..7] of the pair's 8 channels: the even lane needs lo[0..3] (odd's first
-                // half), the odd lane hi[4..7] (even's second half)
-                const uint4 q = *reinterpret_cast<const uint4*>(&ad[g]);
-                const unsigned sx = odd ? q.x : q.z, sy = odd ? q.y : q.w;
-                const unsigned rx = lane_xor1(sx), ry = lane_xor1(sy);
-                const unsigned hx = odd ? rx : q.x, hy = odd ? ry : q.y, lx = odd ? q.z : rx, ly = odd ? q.w : ry;
-                fmt_value2(hx, lx, &ad[g].x, &ad[g].y);
-                fmt_value2(hy, ly, &ad[g].z, &ad[g].w);
-              }
-              if (has_mask && mask_pl) {
-                const uint4 q = *reinterpret_cast<const uint4*>(&mk[g]);
-                const unsigned rx = lane_xor1(q.z), ry = lane_xor1(q.w);  // the even lane's second half
-                const unsigned hx = odd ? rx : q.x, hy = odd ? ry : q.y;
-                mk[g] = make_float4(fmt_pos(hx & 0xffffu) ? 1.f : 0.f, fmt_pos(hx >> 16) ? 1.f : 0.f, fmt_pos(hy & 0xffffu) ? 1.f : 0.f,
-                                    fmt_pos(hy >> 16) ? 1.f : 0.f);
-              }
-              if (has_add) { v.x += ad[g].x; v.y += ad[g].y; v.z += ad[g].z; v.w += ad[g].w; }
-              if (has_mask) {
-                v.x = mk[g].x > 0.f ? v.x : 0.f; v.y = mk[g].y > 0.f ? v.y : 0.f;
-                v.z = mk[g].z > 0.f ? v.z : 0.f; v.w = mk[g].w > 0.f ? v.w : 0.f;
-              }
-              if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-              // XR (igemm3x): tile rows 0 and BM - 1 are halo rows that the neighbouring tiles own
-              const int trow = hm * 32 * TM + a0 * 32 + row;
-              if (m <= m_last && (!XR || (trow >= 1 && trow <= 32 * TM * NWM - 2))) {
-                if (!OP || g_out != nullptr) *reinterpret_cast<float4*>(g_out + (long long)mo[g] * p.ld_out + co) = v;
-              }
-              if (OP) {
-                // the output as packed planes: lanes 2j / 2j + 1 hold channels 8j .. 8j+3 / 8j+4 .. 8j+7 of the same row; they swap
-                // halves so that the even lane stores the group's 16 hi bytes and the odd lane its 16 lo bytes (one 16-byte
-                // store per lane, like the float32 tile; Nout % 8 == 0 is host-checked, so both lanes of a pair are in range)
-                uint2 oh, ol;
-                split4(v, &oh, &ol);
-                const unsigned sx = odd ? oh.x : ol.x, sy = odd ? oh.y : ol.y;
-                const unsigned rx = lane_xor1(sx), ry = lane_xor1(sy);
-                const uint4 o16 = odd ? make_uint4(rx, ry, ol.x, ol.y) : make_uint4(oh.x, oh.y, rx, ry);
-                if (m <= m_last && (!XR || (trow >= 1 && trow <= 32 * TM * NWM - 2))) {
-                  const long long grp = ((long long)mo[g] * p.ld_out + (co & ~7)) >> 3;  // 32-byte group
-                  reinterpret_cast<uint4*>(g_ohi)[2 * grp + (odd ? 1 : 0)] = o16;
-                }
-              }
-            }
-          }
-        };
-        const bool any_add = g_addend != nullptr || add_pl, any_mask = g_mask != nullptr || mask_pl;
-        if (any_add && any_mask) sweep(std::true_type{}, std::true_type{});
-        else if (any_add) sweep(std::true_type{}, std::false_type{});
-        else if (any_mask) sweep(std::false_type{}, std::true_type{});
-        else sweep(std::false_type{}, std::false_type{});
-      }
-    }
-  }
-}
+#include "conv3_shared.h"
 
 template <int TM, int TN, bool AP, bool OP>
 __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4)) void igemm3_kernel(
@@ -403,20 +186,6 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
 // whose out-of-range offsets return zeros -- padding taps and rows past M need no branch, so the whole k-loop body
 // is ONE basic block that the scheduler can interleave under the MFMAs.  Buffers must stay below 2 GiB
 // (host-checked; larger tensors take igemm3_kernel).
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-#define PP_BUF_OOB ((int)0x80000000)
-
-__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-  return make_uint4(v.x, v.y, v.z, v.w);
-}
-
-__device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, const uint4& v, int voff) {
-  u32x4 q;
-  q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
-  __builtin_amdgcn_raw_buffer_store_b128(q, r, voff, 0, 0);  // out-of-range offsets are dropped
-}
-
 // Measured and NOT kept (tools/conv_bench.py --shape r3 = exactly three rounds of workgroups, 128x128 tile): a 64-deep k-step
 // (twice the MFMAs per barrier pair, 2 workgroups/CU) and register double-buffering of the staged tiles (loads issued two
 // steps ahead, 190 VGPRs, 2 workgroups/CU) both land on the same 340-355 TFLOP/s as this loop; dependent MFMAs on one
@@ -931,15 +700,19 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
 // 3x3 stride 1, kernel row innermost (x_ty_inner), w_rows % 128 == 0, at least two rounds of tiles (PP_CONV3_DMA_MIN).
 // Measured (P16, same box): 422-434 us against 499 on a tail-free 512-channel shape (1.16x), the regression-head launch 486 against
 // 577 us (1.19x, 490 TFLOP/s); bf16 pairs 1.04x; training step +3.1 %.
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, uint4* lds, int voff, int soff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
-}
-template <bool OP, int VAR = 0>
-__global__ __launch_bounds__(512, 1) void igemm4x_kernel(
+// NWM = 4: the form above (8 waves, 256 x 128, one workgroup per CU, weight ring of three stages = 112 KB of LDS).
+// NWM = 2 (round 4): 4 waves, 128 x 128, TWO workgroups per CU -- gathered ring of 2 x 16 KB + weight ring of 2 x 16 KB = 64 KB
+// each -- for the launches that cannot fill two rounds of 256-row tiles (the 256-channel heads, the FPN 3x3): the weight tile is
+// fetched ONE tap ahead (into the stage the previous tap has just left), the gathered tile two taps ahead; the second workgroup
+// of the CU covers the waits.  Same products in the same order as igemm3x either way.
+template <bool OP, int VAR = 0, int NWM = 4>
+__global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void igemm4x_kernel(
     const IgemmParams p, const void* __restrict__ g_a, const void* __restrict__ g_a1, unsigned a_bytes, const void* __restrict__ g_whi,
     const void* __restrict__ g_wlo, unsigned w_bytes, const float* __restrict__ g_bias, const float* __restrict__ g_addend,
     const float* __restrict__ g_mask, float* __restrict__ g_out, uint2* __restrict__ g_ohi, uint2* __restrict__ g_olo, int w_rows, int w_ld8) {
-  constexpr int TM = 2, TN = 2, NWM = 4, BM = 32 * TM * NWM, BN = 128, BK = 32, NO = BK / 8, ES = 4;
+  constexpr int TM = 2, TN = 2, NW = 2 * NWM, BM = 32 * TM * NWM, BN = 128, BK = 32, NO = BK / 8, ES = 4;
+  constexpr int BST = NWM == 4 ? 3 : 2;  // stages of the weight ring
+  constexpr int BI = 128 / (16 * NW);    // LDS-DMA instructions per wave and weight plane (16 rows x 64 bytes each)
   constexpr int A_STAGE = 8 * BM + 2, B_STAGE = 2 * NO * BN;  // (gathered: 8 pieces per row + the two zero slots; weights: hi + lo regions)
   // every stage is an LDS object of its own: the compiler's LDS-DMA tracking (alias scopes per object) then inserts COUNTED vmcnt
   // waits in front of a fragment read -- for the DMA into that stage only -- instead of draining everything in flight
@@ -947,9 +720,12 @@ __global__ __launch_bounds__(512, 1) void igemm4x_kernel(
   __shared__ __attribute__((aligned(16))) uint4 sA1[A_STAGE];
   __shared__ __attribute__((aligned(16))) uint4 sB0[B_STAGE];
   __shared__ __attribute__((aligned(16))) uint4 sB1[B_STAGE];
-  __shared__ __attribute__((aligned(16))) uint4 sB2[B_STAGE];
+  __shared__ __attribute__((aligned(16))) uint4 sB2[BST == 3 ? B_STAGE : 1];
   auto stA = [&](auto k) -> uint4* {
     if constexpr (decltype(k)::value == 0) return sA0; else return sA1;
+  };
+  auto stB = [&](auto k) -> uint4* {
+    if constexpr (decltype(k)::value == 0) return sB0; else return sB1;
   };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -969,7 +745,7 @@ __global__ __launch_bounds__(512, 1) void igemm4x_kernel(
   // DMA lanes (LDS images of planes_fmt.h LAY 1, filled in FULL lines).  Gathered tile: one instruction = 8 rows x 8 pieces (the
   // 128 contiguous bytes [hi0 lo0 .. hi3 lo3] of a row's 32-channel chunk); wave w owns rows 32 w .. 32 w + 31 in four instructions;
   // the lane at LDS piece position q of row r fetches piece q ^ ((r / 2) mod 8).  Weight tile, per plane: one instruction = 16
-  // rows x 4 pieces (64 contiguous bytes); wave w owns rows 16 w .. 16 w + 15; piece q of row n is octet q ^ ((n / 4) mod 4).
+  // rows x 4 pieces (64 contiguous bytes); wave w owns rows 16 (BI w + i) .. + 15, i < BI; piece q of row n is octet q ^ ((n / 4) mod 4).
   int s_base[4], s_pitch[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -985,9 +761,13 @@ __global__ __launch_bounds__(512, 1) void igemm4x_kernel(
       if (ok && (unsigned)(r.ybase + ty * p.tsign) < (unsigned)r.SH) v |= 1 << ty;
     s_pitch[c] = (p.tsign * r.SW * p.ld_src * ES) | v;
   }
-  const int b_row = 16 * wave + (lane >> 2);
-  const int b_n = n0 + b_row;
-  const int b_dma = b_n < w_rows ? (b_n * w_ld8 + ((lane & 3) ^ ((b_row >> 2) & 3))) * 16 : PP_BUF_OOB;
+  int b_dma[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int b_row = 16 * (BI * wave + i) + (lane >> 2);
+    const int b_n = n0 + b_row;
+    b_dma[i] = b_n < w_rows ? (b_n * w_ld8 + ((lane & 3) ^ ((b_row >> 2) & 3))) * 16 : PP_BUF_OOB;
+  }
   const int b_tap = w_rows * w_ld8 * 16;
 
   unsigned f_valid = 0;
@@ -1018,9 +798,12 @@ __global__ __launch_bounds__(512, 1) void igemm4x_kernel(
   auto dma_b = [&](int g, int tx, uint4* st) {  // the weight tile of tap (group g, tx) -> stage st
     const int ty = g % 3, chunk = g / 3;
     const int b_uni = ((p.w_ty0 + ty) * p.w_kw + tx) * b_tap + chunk * (BK / 8 * 16);
-    uint4* const hi = st + 4 * 16 * wave;
-    dma16(rs_wh, hi, b_dma, b_uni);
-    dma16(rs_wl, hi + NO * BN, b_dma, b_uni);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      uint4* const hi = st + 4 * 16 * (BI * wave + i);
+      dma16(rs_wh, hi, b_dma[i], b_uni);
+      dma16(rs_wl, hi + NO * BN, b_dma[i], b_uni);
+    }
   };
 
   floatx16 acc[TM][TN];
@@ -1044,32 +827,54 @@ __global__ __launch_bounds__(512, 1) void igemm4x_kernel(
   };
   std::integral_constant<int, 0> c0;
   std::integral_constant<int, 1> c1;
-  // Weight ring of THREE stages: the stage of a tap is its tx (compile time without unrolling over groups), the tile of tap t + 2
-  // goes into the stage tap t - 1 has just left; gathered ring of two stages (unrolled over two groups), loaded one group ahead.
+  auto tap_end = [&](auto n) {  // all but the n youngest DMAs of this wave have landed; then every wave's have
+    constexpr int N = decltype(n)::value;
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else static_assert(N == 0, "tap_end: count");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  // BST == 3: weight ring of THREE stages: the stage of a tap is its tx (compile time without unrolling over groups), the tile of tap
+  // t + 2 goes into the stage tap t - 1 has just left; gathered ring of two stages (unrolled over two groups), loaded one group ahead.
   // Issue order at a tap's start: [gathered tile of the next group, at tx == 0], weight tile of tap t + 2.  At the end of tap t the
   // tile of tap t + 1 (issued at tap t - 1) must have landed: instructions issued after it = tx 0: 4 (A) + 2 = 6; tx 1: 2;
   // tx 2: 2 -- and the gathered tile of group g + 1 (issued at tx 0, before the weight tile waited for at tx 1) is then in.
+  // BST == 2: the stage of a tap is the parity of its index in a PAIR of groups (u = 3 K + tx); at a tap's start the weight tile of
+  // tap t + 1 goes into the other stage (all waves have left it: the barrier that ended tap t - 1), then -- at tx == 0 -- the
+  // gathered tile of the next group; at the tap's end the weight tile must be in: everything but the 4 gathered DMAs issued behind
+  // it at tx 0 (they have until the end of tx 1), everything at tx 1 and tx 2.
   auto group = [&](int g, auto k) {
     constexpr int K = decltype(k)::value;
     const int c_ty = g % 3;
     const int gn = g + 1 < G ? g + 1 : 0;  // past the end: group 0 again (a harmless re-load)
     uint4* const Ahi = stA(std::integral_constant<int, K & 1>{});
-    dma_a(gn, stA(std::integral_constant<int, (K + 1) & 1>{}));
-    dma_b(g, 2, sB2);
-    mma_tile(c_ty, 0, Ahi, sB0);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    dma_b(gn, 0, sB0);
-    mma_tile(c_ty, 1, Ahi, sB1);
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    dma_b(gn, 1, sB1);
-    mma_tile(c_ty, 2, Ahi, sB2);
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    if constexpr (BST == 3) {
+      dma_a(gn, stA(std::integral_constant<int, (K + 1) & 1>{}));
+      dma_b(g, 2, sB2);
+      mma_tile(c_ty, 0, Ahi, sB0);
+      tap_end(std::integral_constant<int, 6>{});
+      dma_b(gn, 0, sB0);
+      mma_tile(c_ty, 1, Ahi, sB1);
+      tap_end(std::integral_constant<int, 2>{});
+      dma_b(gn, 1, sB1);
+      mma_tile(c_ty, 2, Ahi, sB2);
+      tap_end(std::integral_constant<int, 2>{});
+    } else {
+      constexpr int U = 3 * K;
+      dma_b(g, 1, stB(std::integral_constant<int, (U + 1) & 1>{}));
+      dma_a(gn, stA(std::integral_constant<int, (K + 1) & 1>{}));
+      mma_tile(c_ty, 0, Ahi, stB(std::integral_constant<int, U & 1>{}));
+      tap_end(std::integral_constant<int, 4>{});
+      dma_b(g, 2, stB(std::integral_constant<int, U & 1>{}));
+      mma_tile(c_ty, 1, Ahi, stB(std::integral_constant<int, (U + 1) & 1>{}));
+      tap_end(std::integral_constant<int, 0>{});
+      dma_b(gn, 0, stB(std::integral_constant<int, (U + 1) & 1>{}));
+      mma_tile(c_ty, 2, Ahi, stB(std::integral_constant<int, U & 1>{}));
+      tap_end(std::integral_constant<int, 0>{});
+    }
   };
 
   if (tid == 0) {  // the two all-zero slots (hi, lo = slot ^ 1) behind each gathered stage
@@ -1078,13 +883,15 @@ __global__ __launch_bounds__(512, 1) void igemm4x_kernel(
     sA1[8 * BM] = make_uint4(0u, 0u, 0u, 0u);
     sA1[8 * BM + 1] = make_uint4(0u, 0u, 0u, 0u);
   }
-  // prologue: group 0 and the weight tiles of taps 0, 1
+  // prologue: group 0 and the weight tiles of taps 0, 1 (BST == 2: of tap 0)
   dma_a(0, sA0);
   dma_b(0, 0, sB0);
-  dma_b(0, 1, sB1);
-  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
+  if constexpr (BST == 3) {
+    dma_b(0, 1, sB1);
+    tap_end(std::integral_constant<int, 2>{});
+  } else {
+    tap_end(std::integral_constant<int, 0>{});
+  }
   for (int g = 0; g < G; g += 2) {
     group(g, c0);
     if (g + 1 >= G) break;
@@ -1092,7 +899,8 @@ __global__ __launch_bounds__(512, 1) void igemm4x_kernel(
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the look-ahead loads of a group that never comes: landed before LDS is reused
   __syncthreads();
-  epilogue3<TM, TN, OP, 4, false, true, false, NWM, 512>(p, acc, sA0, m0, n0, tid, wm, wn, il, h, g_bias, g_addend, g_mask, g_out, g_ohi, g_olo);
+  // (NWM == 2: a gathered stage holds 16 KB, so the epilogue stages 32 rows at a time)
+  epilogue3<TM, TN, OP, 4, false, true, false, NWM, 128 * NWM, (NWM == 2 ? 1 : 0)>(p, acc, sA0, m0, n0, tid, wm, wn, il, h, g_bias, g_addend, g_mask, g_out, g_ohi, g_olo);
 }
 
 // epilogue arithmetic of the pointwise finishing kernels: v (+ addend) (masked by the ReLU source) (ReLU) -> f32 and / or planes;
@@ -1707,6 +1515,18 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
             }
             return;
           }
+          // Round 4: launches too small for two rounds of 256-row tiles (the 256-channel heads, the FPN 3x3: 1.2-1.6 rounds of 128-row
+          // tiles on 2 x 256 slots) take the 128 x 128 form of the same pipeline, two workgroups per CU (PP_CONV3_DMA2=0: igemm3x;
+          // PP_CONV3_DMA2_MIN: fewest 128-row tiles, default one round)
+          const char* const e_dma2 = getenv("PP_CONV3_DMA2");  // (per launch, like PP_CONV3_DMA)
+          const bool dma2_on = !(e_dma2 && e_dma2[0] == '0');
+          static const int dma2_min = []() { const char* e = getenv("PP_CONV3_DMA2_MIN"); return e ? atoi(e) : 512; }();
+          if (dma2_on && n_tiles_mx * ntn >= dma2_min) {
+            p.n_tiles_n = ntn;
+            hipLaunchKernelGGL((igemm4x_kernel<true, 1, 2>), dim3((unsigned)(n_tiles_mx * ntn)), dim3(256), 0, st, p, ahi, alo, (unsigned)a_bytes, whi,
+                               wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)ohi, (uint2*)olo, w_rows, w_ld8);
+            return;
+          }
         }
       }
       if (ahi && op)
@@ -1807,6 +1627,42 @@ static void dispatch3(pp_ctx* ctx, IgemmParams& p, const void* ahi, const void* 
                       int w_ld8, void* ohi, void* olo, void* chi = nullptr, void* clo = nullptr, const unsigned char* flags = nullptr) {
   int tm, tn, splits;
   const int n_steps = p.kh * p.kw * (p.Cred / 32);
+  {
+    // Round 4: 1x1 convolutions on plane-stored operands (the bottleneck branches of the backbone, the FPN laterals; forward and
+    // stride-1 data gradient) -> the persistent LDS-DMA GEMM of conv4.hip.  PP_CONV4P=0: the register-staged kernels below;
+    // PP_CONV4P_NST: stages of its ring (4 = all of the CU's LDS, default; 3); PP_CONV4P_SPLITS forces the reduction split.
+    // (read at every launch: tests compare the two kernels inside one process)
+    const char* const e_on = getenv("PP_CONV4P");
+    const char* const e_nst = getenv("PP_CONV4P_NST");
+    const char* const e_sp = getenv("PP_CONV4P_SPLITS");
+    const bool p_on = !(e_on && e_on[0] == '0');
+    const int p_nst = e_nst && atoi(e_nst) == 3 ? 3 : 4;
+    const int p_splits = e_sp ? atoi(e_sp) : 0;
+    const long long a_bytes = p.src_rows * (long long)p.ld_src * 4, w_bytes = (long long)p.w_taps * w_rows * w_ld8 * 16;
+    if (p_on && p.kh == 1 && p.kw == 1 && ahi && !chi && !flags && !p.sc_on && p.div == 1 && p.Cred % 32 == 0 && p.ld_src % 8 == 0 &&
+        a_bytes < (1ll << 31) && w_bytes < (1ll << 31) && p.src_rows > 0 && (ohi || p.out)) {
+      const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+      const long long tiles = (long long)((p.M + 127) / 128) * ((p.Nout + 127) / 128);
+      int sp = 1;
+      if (tiles * 4 < (long long)n_cu * 3 && ctx->ws != nullptr) {  // under three quarters of a round: split the reduction to fill the chip
+        sp = (int)(n_cu / tiles);
+        while (sp > 1 && (n_steps / sp < 4 || (long long)sp * p.M * p.ld_out * 4 > (long long)ctx->ws_bytes)) --sp;
+      }
+      if (p_splits >= 1 && (p_splits == 1 || (ctx->ws != nullptr && n_steps / p_splits >= 1 && (long long)p_splits * p.M * p.ld_out * 4 <= (long long)ctx->ws_bytes)))
+        sp = p_splits;
+      if (getenv("PP_CONV_DEBUG"))
+        fprintf(stderr, "igemm4p M %d N %d steps %d -> %lld tiles x %d splits on %d CUs, %d stages\n", p.M, p.Nout, n_steps, tiles, sp, n_cu, p_nst);
+      PP_API(pp4_launch_igemm4p)(ctx->stream, p, ahi, whi, wlo, w_rows, w_ld8, ohi, olo, sp, sp > 1 ? ctx->ws : nullptr, n_cu, p_nst);
+      if (sp > 1) {
+        const long long total = (long long)p.M * ((p.Nout + 3) >> 2);
+        long long blocks = (total + 255) / 256;
+        if (blocks > (long long)n_cu * 8) blocks = (long long)n_cu * 8;
+        hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p, sp, ctx->ws, p.bias, p.addend, p.mask_src, p.out,
+                           ohi, olo);
+      }
+      return;
+    }
+  }
   const bool may_split = ctx->ws != nullptr && (ohi || p.out != nullptr) && !p.sc_on && igemm3_fast_ok(p, ahi != nullptr, w_rows, w_ld8);
   pick_tile3(ctx, p.M, p.Nout, p.ld_out, n_steps, may_split, igemm3x_ok(p, ahi != nullptr, ohi != nullptr, w_rows, w_ld8), &tm, &tn, &splits);
   if (getenv("PP_CONV_DEBUG"))

@@ -538,3 +538,117 @@ def test_lds_dma_kernel_matches_register_staged(ctx, monkeypatch):
     ref = torch.relu(F.conv2d(xi, wt, bias.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, cout) + merged(rp).double())
     err = (out["1"][2].double() - ref).abs().max() / ref.abs().max()
     assert float(err) <= (1e-4 if FMT[0] == 1 else 3e-5), float(err)
+
+
+def test_lds_dma_kernel_two_workgroups_per_cu_matches_register_staged(ctx, monkeypatch):
+    """Round 4, igemm4x<NWM = 2> (csrc/conv3.hip): the 128 x 128 form of the LDS-DMA pipeline, two workgroups per CU, gathered ring
+    2 x 16 KB + weight ring 2 x 16 KB -- taken by launches between one round of 128-row tiles and two rounds of 256-row tiles (the
+    256-channel heads, the FPN 3x3).  Same products in the same order as igemm3x: EVERY row bit-identical (PP_CONV3_DMA2=0 / 1,
+    read per launch); forward with bias + residual + ReLU over a three-level row space, data gradient with addend + mask."""
+    from pyrapose_amd import ops
+    rng = np.random.default_rng(41)
+    B, shapes, cin, cout, k = 2, [(60, 80), (30, 40), (15, 20)], 64, 256, 3     # 12 600 rows -> 100 row tiles x 2 = 200 tiles
+    rows = sum(B * h * w for h, w in shapes)
+    d = ops.make_conv_desc(B, shapes, shapes, cin, cout, k, 1, 1, 1, cin, cout, cout)
+    dT = ops.make_conv_desc(B, shapes, shapes, cout, cout, k, 1, 1, 1, cout, cout, cout)
+    x = torch.as_tensor(rng.standard_normal((rows, cin)), dtype=torch.float32).cuda()
+    w = torch.as_tensor(rng.standard_normal((k * k * cin, cout)) * 0.05, dtype=torch.float32).cuda()
+    w2 = torch.as_tensor(rng.standard_normal((k * k * cout, cout)) * 0.02, dtype=torch.float32).cuda()
+    bias = torch.as_tensor(rng.standard_normal((cout,)), dtype=torch.float32).cuda()
+    res = torch.as_tensor(rng.standard_normal((rows, cout)), dtype=torch.float32).cuda()
+    dy = torch.as_tensor(rng.standard_normal((rows, cout)), dtype=torch.float32).cuda()
+    i16 = dict(dtype=torch.int16, device="cuda")
+    fh, fl = torch.zeros((k * k, cout, cin), **i16), torch.zeros((k * k, cout, cin), **i16)
+    dh, dl = torch.zeros((k * k, cin, cout), **i16), torch.zeros((k * k, cin, cout), **i16)
+    ops.conv_split_weights3(ctx, d, w, fh, fl, dh, dl)
+    f2h, f2l = torch.zeros((k * k, cout, cout), **i16), torch.zeros((k * k, cout, cout), **i16)
+    d2h, d2l = torch.zeros((k * k, cout, cout), **i16), torch.zeros((k * k, cout, cout), **i16)
+    ops.conv_split_weights3(ctx, dT, w2, f2h, f2l, d2h, d2l)
+    xp, rp, gp = split(ctx, x), split(ctx, res), split(ctx, dy)
+    out = {}
+    monkeypatch.setenv("PP_CONV3_DMA2_MIN", "1")      # (the default asks for a full round of tiles: this shape has 200)
+    monkeypatch.setenv("PP_CONV3_TILE", "2,2")
+    try:
+        for dma in ("0", "1"):
+            monkeypatch.setenv("PP_CONV3_DMA2", dma)
+            yp = nan_planes(res)
+            ops.conv_fwd3(ctx, d, None, fh, fl, bias, None, True, None, x_planes=xp, y_planes=yp, res_planes=rp)
+            dxp = nan_planes(res)
+            ops.conv_bwd_data3(ctx, dT, None, d2h, d2l, None, None, None, dy_planes=gp, dx_planes=dxp, addend_planes=rp, relu_src_hi=rp[0])
+            torch.cuda.synchronize()
+            out[dma] = (raw(yp), raw(dxp), merged(yp))
+    finally:
+        monkeypatch.delenv("PP_CONV3_DMA2", raising=False)
+    for i in (0, 1):
+        (ah, al), (bh, bl) = out["0"][i], out["1"][i]
+        assert torch.equal(ah, bh) and torch.equal(al, bl), i
+    assert not torch.isnan(out["1"][2]).any() and float(out["1"][2].abs().max()) > 0
+
+
+@pytest.mark.parametrize("case", ["res5c_2c", "res4a_1_s2", "res3_2a_dgrad", "small_split"])
+def test_persistent_1x1_gemm_matches_register_staged(ctx, monkeypatch, case):
+    """Round 4, igemm4p_kernel (csrc/conv4.hip): the 1x1 convolutions as a persistent LDS-DMA GEMM (ring of 3 / 4 stages, items =
+    tiles x reduction splits walked by one workgroup per CU).  Unsplit: same products in the same order as igemm3f -> bit-identical
+    planes (PP_CONV4P=0 / 1, read per launch); with the reduction split: f32 summation order.  Cases: branch2c with residual + ReLU
+    (2 400 rows, 512 -> 2 048: more tiles than CUs -> several items per workgroup), a stride-2 projection, a data gradient with
+    addend + ReLU mask, and a launch small enough to be split."""
+    from pyrapose_amd import ops
+    rng = np.random.default_rng(43)
+    cfg = {"res5c_2c": (8, [(15, 20)], 512, 2048, 1, "fwd"), "res4a_1_s2": (2, [(60, 80)], 512, 1024, 2, "fwd"),
+           "res3_2a_dgrad": (2, [(60, 80)], 512, 128, 1, "dgrad"), "small_split": (1, [(15, 20)], 2048, 512, 1, "fwd")}[case]
+    B, shapes, cin, cout, stride, kind = cfg
+    out_shapes = [(-(-h // stride), -(-w // stride)) for h, w in shapes]
+    rows_in, rows = sum(B * h * w for h, w in shapes), sum(B * h * w for h, w in out_shapes)
+    d = ops.make_conv_desc(B, shapes, out_shapes, cin, cout, 1, stride, 0, 0, cin, cout, cout)
+    x = torch.as_tensor(rng.standard_normal((rows_in, cin)), dtype=torch.float32).cuda()
+    w = torch.as_tensor(rng.standard_normal((cin, cout)) * 0.05, dtype=torch.float32).cuda()
+    bias = torch.as_tensor(rng.standard_normal((cout,)), dtype=torch.float32).cuda()
+    res = torch.as_tensor(rng.standard_normal((rows, cout)), dtype=torch.float32).cuda()
+    dy = torch.as_tensor(rng.standard_normal((rows, cout)), dtype=torch.float32).cuda()
+    addend = torch.as_tensor(rng.standard_normal((rows_in, cin)), dtype=torch.float32).cuda()
+    i16 = dict(dtype=torch.int16, device="cuda")
+    fh, fl = torch.zeros((1, cout, cin), **i16), torch.zeros((1, cout, cin), **i16)
+    dh, dl = torch.zeros((1, cin, cout), **i16), torch.zeros((1, cin, cout), **i16)
+    ops.conv_split_weights3(ctx, d, w, fh, fl, dh, dl)
+    xp, rp, gp, ap = split(ctx, x), split(ctx, res), split(ctx, dy), split(ctx, addend)
+    out = {}
+    ctx.set_workspace(64 << 20)
+    try:
+        for variant in ("0", "1", "3", "s"):
+            monkeypatch.setenv("PP_CONV4P", "0" if variant == "0" else "1")
+            monkeypatch.setenv("PP_CONV4P_NST", "3" if variant == "3" else "4")
+            if variant == "s":
+                monkeypatch.delenv("PP_CONV4P_SPLITS", raising=False)   # the launcher's own choice (splits the small case)
+            else:
+                monkeypatch.setenv("PP_CONV4P_SPLITS", "1")
+                monkeypatch.setenv("PP_CONV3_SPLITS", "1")
+            if kind == "fwd":
+                yp = nan_planes(res)
+                ops.conv_fwd3(ctx, d, None, fh, fl, bias, None, True, None, x_planes=xp, y_planes=yp, res_planes=rp)
+            else:
+                yp = nan_planes(addend)
+                ops.conv_bwd_data3(ctx, d, None, dh, dl, None, None, None, dy_planes=gp, dx_planes=yp, addend_planes=ap, relu_src_hi=xp[0])
+            torch.cuda.synchronize()
+            out[variant] = (raw(yp), merged(yp))
+    finally:
+        ctx.set_workspace(0)
+        for k_ in ("PP_CONV4P", "PP_CONV4P_NST", "PP_CONV4P_SPLITS", "PP_CONV3_SPLITS"):
+            monkeypatch.delenv(k_, raising=False)
+    (ah, al), va = out["0"]
+    assert not torch.isnan(va).any() and float(va.abs().max()) > 0
+    for variant in ("1", "3"):
+        (bh, bl), _ = out[variant]
+        assert torch.equal(ah, bh) and torch.equal(al, bl), variant
+    vs = out["s"][1]
+    assert not torch.isnan(vs).any()
+    assert float((va - vs).abs().max()) <= (8e-5 if FMT[0] == 1 else 4e-5) * float(va.abs().max())
+    # float64 reference
+    xv, wv = merged(xp).double(), w.double()
+    if kind == "fwd":
+        h0, w0 = shapes[0]
+        xs = xv.reshape(B, h0, w0, cin)[:, ::stride, ::stride, :].reshape(-1, cin)
+        ref = torch.relu(xs @ wv + bias.double() + merged(rp).double())
+    else:
+        ref = (merged(gp).double() @ wv.t() + merged(ap).double()) * (xv > 0)
+    err = (va.double() - ref).abs().max() / ref.abs().max()
+    assert float(err) <= (1e-4 if FMT[0] == 1 else 3e-5), float(err)

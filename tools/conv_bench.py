@@ -23,6 +23,10 @@ SHAPES = {
     "res5a": (8, [(15, 20)], 2048, 512, 1, 1, 0),
     "res4": (8, [(30, 40)], 256, 256, 3, 1, 1),
     "res4c": (8, [(30, 40)], 256, 1024, 1, 1, 0),
+    "res4a": (8, [(30, 40)], 1024, 256, 1, 1, 0),
+    "res3a": (8, [(60, 80)], 512, 128, 1, 1, 0),
+    "fpnmid": (8, [(60, 80)], 256, 256, 3, 1, 1),
+    "lat3": (8, [(60, 80)], 512, 256, 1, 1, 0),
     "res3": (8, [(60, 80)], 128, 128, 3, 1, 1),
     "res3c": (8, [(60, 80)], 128, 512, 1, 1, 0),
     "res2c": (8, [(120, 160)], 64, 256, 1, 1, 0),
@@ -60,6 +64,9 @@ def main():
     ap.add_argument("--check", action="store_true", help="print the error of the forward modes against a float64 convolution")
     ap.add_argument("--fmt", type=int, default=0, choices=[0, 1],
                     help="plane format / arithmetic of the *3* modes: 0 = bf16 pairs (bf16x3), 1 = P16 (f16c8)")
+    ap.add_argument("--ab", default="", help="ENV=a,b[,c]: time every mode once per value of an environment switch that the library reads "
+                    "at every launch (PP_CONV3_DMA, PP_CONV3_DMA2, PP_CONV4P, PP_CONV4P_NST, PP_WGRAD4): interleaved rounds in ONE process")
+    ap.add_argument("--rounds", type=int, default=3, help="with --ab: rounds over the values (the fastest round of each is printed too)")
     args = ap.parse_args()
     ctx = ops.Context(0)
     if args.fmt:
@@ -143,16 +150,33 @@ def main():
                "wgrad": lambda: ops.conv_bwd_weight(ctx, d, x, dy, dw, db)}
         for mode in args.mode.split(","):
             fn = fns[mode]
-            for _ in range(3):
-                fn()
-            torch.cuda.synchronize()
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            for _ in range(args.iters):
-                fn()
-            e.record()
-            torch.cuda.synchronize()
-            us = s.elapsed_time(e) * 1e3 / args.iters
+
+            def timed():
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                for _ in range(args.iters):
+                    fn()
+                e.record()
+                torch.cuda.synchronize()
+                return s.elapsed_time(e) * 1e3 / args.iters
+            if args.ab:
+                key, vals = args.ab.split("=")
+                vals = vals.split(",")
+                res = {v: [] for v in vals}
+                for _ in range(args.rounds):
+                    for v in vals:
+                        os.environ[key] = v
+                        res[v].append(timed())
+                os.environ.pop(key, None)
+                for v in vals:
+                    med, best = sorted(res[v])[len(res[v]) // 2], min(res[v])
+                    print("%-7s %-8s %s=%-3s rows=%d cin=%d cout=%d k=%d  median %.1f us (%.1f TFLOP/s)  best %.1f us" %
+                          (name, mode, key, v, rows, cin, cout, k, med, flops / med / 1e6, best), flush=True)
+                continue
+            us = timed()
             tf = flops / us / 1e6
             print("%-7s %-6s rows=%d cin=%d cout=%d k=%d  %.1f us  %.1f TFLOP/s  %.1f%% of f32-MFMA peak" %
                   (name, mode, rows, cin, cout, k, us, tf, 100 * tf / 157.3), flush=True)
