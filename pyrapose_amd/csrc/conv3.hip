@@ -38,6 +38,10 @@ namespace {
 
 #include "conv3_shared.h"
 
+#ifndef PP_EPI_GF
+#define PP_EPI_GF 4  // output rows in flight per thread in igemm3f's epilogue (8 measured in round 4: see DESIGN.md)
+#endif
+
 template <int TM, int TN, bool AP, bool OP>
 __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4)) void igemm3_kernel(
     const IgemmParams p, const float* __restrict__ g_src, const uint4* __restrict__ g_ahi, const uint4* __restrict__ g_alo,
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 2 : ((TM * TN == 4) ? 3 : 4))
       }
     return;
   }
-  epilogue3<TM, TN, OP, 4, SC, false, RL>(p, acc, smem, m0, n0, tid, wm, wn, il, h, g_bias, g_addend, g_mask, g_out, g_ohi, g_olo, rl_blk);
+  epilogue3<TM, TN, OP, PP_EPI_GF, SC, false, RL>(p, acc, smem, m0, n0, tid, wm, wn, il, h, g_bias, g_addend, g_mask, g_out, g_ohi, g_olo, rl_blk);
 }
 
 // ---- igemm3x: 3-wide stride-1 "same" convolutions with the gathered tile shared by the three taps of a kernel row ----
@@ -1516,10 +1520,12 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
             return;
           }
           // Round 4: launches too small for two rounds of 256-row tiles (the 256-channel heads, the FPN 3x3: 1.2-1.6 rounds of 128-row
-          // tiles on 2 x 256 slots) take the 128 x 128 form of the same pipeline, two workgroups per CU (PP_CONV3_DMA2=0: igemm3x;
+          // tiles on 2 x 256 slots) CAN take the 128 x 128 form of the same pipeline, two workgroups per CU (PP_CONV3_DMA2=1: opt-in;
           // PP_CONV3_DMA2_MIN: fewest 128-row tiles, default one round)
           const char* const e_dma2 = getenv("PP_CONV3_DMA2");  // (per launch, like PP_CONV3_DMA)
-          const bool dma2_on = !(e_dma2 && e_dma2[0] == '0');
+          // (off by default: +8 % on the class-head launch, -8 % on the mask head / FPN launches -- 610 tiles on 512 slots --, -2 % on
+          // the training step, profiles/r04_lds_dma_128_row_tiles.txt)
+          const bool dma2_on = e_dma2 && e_dma2[0] == '1';
           static const int dma2_min = []() { const char* e = getenv("PP_CONV3_DMA2_MIN"); return e ? atoi(e) : 512; }();
           if (dma2_on && n_tiles_mx * ntn >= dma2_min) {
             p.n_tiles_n = ntn;
@@ -1629,13 +1635,14 @@ static void dispatch3(pp_ctx* ctx, IgemmParams& p, const void* ahi, const void* 
   const int n_steps = p.kh * p.kw * (p.Cred / 32);
   {
     // Round 4: 1x1 convolutions on plane-stored operands (the bottleneck branches of the backbone, the FPN laterals; forward and
-    // stride-1 data gradient) -> the persistent LDS-DMA GEMM of conv4.hip.  PP_CONV4P=0: the register-staged kernels below;
+    // stride-1 data gradient) -> the persistent LDS-DMA GEMM of conv4.hip.  OPT-IN (PP_CONV4P=1): bit-identical, but 1.05-1.9x
+    // SLOWER than igemm3f per launch and -7 % on the training step (profiles/r04_1x1_persistent_dma_gemm.txt);
     // PP_CONV4P_NST: stages of its ring (4 = all of the CU's LDS, default; 3); PP_CONV4P_SPLITS forces the reduction split.
     // (read at every launch: tests compare the two kernels inside one process)
     const char* const e_on = getenv("PP_CONV4P");
     const char* const e_nst = getenv("PP_CONV4P_NST");
     const char* const e_sp = getenv("PP_CONV4P_SPLITS");
-    const bool p_on = !(e_on && e_on[0] == '0');
+    const bool p_on = e_on && e_on[0] == '1';  // (off by default: measured slower than igemm3f on every backbone shape, see conv4.hip)
     const int p_nst = e_nst && atoi(e_nst) == 3 ? 3 : 4;
     const int p_splits = e_sp ? atoi(e_sp) : 0;
     const long long a_bytes = p.src_rows * (long long)p.ld_src * 4, w_bytes = (long long)p.w_taps * w_rows * w_ld8 * 16;

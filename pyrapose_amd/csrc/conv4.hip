@@ -31,13 +31,95 @@ namespace {
 #include "planes_fmt.h"
 #include "conv3_shared.h"
 
+// ---- fragment reads out of the compiler's sight ----
+// The k-loop below keeps NST - 1 LDS-DMA batches in flight across its barriers.  hipcc tracks LDS-DMA per LDS object and puts a
+// vmcnt wait in front of every ds_read that may alias a pending batch; across the control flow of this kernel (item boundaries,
+// the epilogue's own waits) its bookkeeping falls back to "any batch", and the wait it inserts -- vmcnt(8): everything but the
+// batch just issued -- turns the ring into a one-step prefetch (first build: 43 us where igemm3f took 28).  So the fragment reads
+// are inline assembly, ordered by hand: [s_waitcnt vmcnt(N); s_barrier] in front of them (step()), then a counted lgkmcnt wait
+// that names every destination register as read-write, so that no MFMA can be scheduled above it
+// (cdna_hip_programming.md section 5.7, form (ii)).
+template <int OFF>
+__device__ __forceinline__ void lds_rd16(u32x4& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF) : "memory");
+}
+#define PP_WAIT8(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7])::"memory")
+#define PP_WAIT4(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])::"memory")
+
+// One 32-deep k-step of a wave's 64 x 64 tile (TM = TN = 2) from a stage at LDS byte address `st` (gathered image at + 0, weight
+// planes at + 16 KB / + 24 KB: planes_fmt.h LAY 1); a_hi / a_lo / b_hi: this lane's fragment offsets [s][block] inside the stage.
+// Same products in the same order as mma_step<2, 2, 128, 128, *, 1> of planes_fmt.h.
+__device__ __forceinline__ void mma_step_asm(floatx16 (&acc)[2][2], unsigned st, const unsigned (&a_hi)[2][2], const unsigned (&a_lo)[2][2],
+                                             const unsigned (&b_hi)[2][2]) {
+  constexpr int BH = 16384, BL = 16384 + 8192;
+#if PP_FMT == 1
+  u32x4 lo[8], h0[4], h1[4];  // lo: [Bl s0 b0, Bl s0 b1, Bl s1 b0, Bl s1 b1, Al s0 a0, Al s0 a1, Al s1 a0, Al s1 a1]
+  lds_rd16<BL>(lo[0], st + b_hi[0][0]); lds_rd16<BL>(lo[1], st + b_hi[0][1]); lds_rd16<BL>(lo[2], st + b_hi[1][0]); lds_rd16<BL>(lo[3], st + b_hi[1][1]);
+  lds_rd16<0>(lo[4], st + a_lo[0][0]); lds_rd16<0>(lo[5], st + a_lo[0][1]); lds_rd16<0>(lo[6], st + a_lo[1][0]); lds_rd16<0>(lo[7], st + a_lo[1][1]);
+  lds_rd16<BH>(h0[0], st + b_hi[0][0]); lds_rd16<BH>(h0[1], st + b_hi[0][1]); lds_rd16<0>(h0[2], st + a_hi[0][0]); lds_rd16<0>(h0[3], st + a_hi[0][1]);
+  lds_rd16<BH>(h1[0], st + b_hi[1][0]); lds_rd16<BH>(h1[1], st + b_hi[1][1]); lds_rd16<0>(h1[2], st + a_hi[1][0]); lds_rd16<0>(h1[3], st + a_hi[1][1]);
+  PP_WAIT8(8, lo);
+  {
+    intx8 bq[2], aq[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      bq[i][0] = (int)lo[i][0]; bq[i][1] = (int)lo[i][1]; bq[i][2] = (int)lo[i][2]; bq[i][3] = (int)lo[i][3];
+      bq[i][4] = (int)lo[2 + i][0]; bq[i][5] = (int)lo[2 + i][1]; bq[i][6] = (int)lo[2 + i][2]; bq[i][7] = (int)lo[2 + i][3];
+      aq[i][0] = (int)lo[4 + i][0]; aq[i][1] = (int)lo[4 + i][1]; aq[i][2] = (int)lo[4 + i][2]; aq[i][3] = (int)lo[4 + i][3];
+      aq[i][4] = (int)lo[6 + i][0]; aq[i][5] = (int)lo[6 + i][1]; aq[i][6] = (int)lo[6 + i][2]; aq[i][7] = (int)lo[6 + i][3];
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq[a], bq[b], acc[a][b], 1, 1, 0, P16_SCALES, 1, P16_SCALES);
+  }
+  PP_WAIT4(4, h0);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(halfx8, h0[2 + a]), __builtin_bit_cast(halfx8, h0[b]), acc[a][b], 0, 0, 0);
+  PP_WAIT4(0, h1);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(halfx8, h1[2 + a]), __builtin_bit_cast(halfx8, h1[b]), acc[a][b], 0, 0, 0);
+#else
+  u32x4 f0[8], f1[8];  // per half-step: [Bh b0, Bh b1, Bl b0, Bl b1, Ah a0, Ah a1, Al a0, Al a1]
+  lds_rd16<BH>(f0[0], st + b_hi[0][0]); lds_rd16<BH>(f0[1], st + b_hi[0][1]); lds_rd16<BL>(f0[2], st + b_hi[0][0]); lds_rd16<BL>(f0[3], st + b_hi[0][1]);
+  lds_rd16<0>(f0[4], st + a_hi[0][0]); lds_rd16<0>(f0[5], st + a_hi[0][1]); lds_rd16<0>(f0[6], st + a_lo[0][0]); lds_rd16<0>(f0[7], st + a_lo[0][1]);
+  lds_rd16<BH>(f1[0], st + b_hi[1][0]); lds_rd16<BH>(f1[1], st + b_hi[1][1]); lds_rd16<BL>(f1[2], st + b_hi[1][0]); lds_rd16<BL>(f1[3], st + b_hi[1][1]);
+  lds_rd16<0>(f1[4], st + a_hi[1][0]); lds_rd16<0>(f1[5], st + a_hi[1][1]); lds_rd16<0>(f1[6], st + a_lo[1][0]); lds_rd16<0>(f1[7], st + a_lo[1][1]);
+  PP_WAIT8(8, f0);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f0[6 + a]), __builtin_bit_cast(bf16x8, f0[b]), acc[a][b], 0, 0, 0);
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f0[4 + a]), __builtin_bit_cast(bf16x8, f0[2 + b]), acc[a][b], 0, 0, 0);
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f0[4 + a]), __builtin_bit_cast(bf16x8, f0[b]), acc[a][b], 0, 0, 0);
+    }
+  PP_WAIT8(0, f1);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f1[6 + a]), __builtin_bit_cast(bf16x8, f1[b]), acc[a][b], 0, 0, 0);
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f1[4 + a]), __builtin_bit_cast(bf16x8, f1[2 + b]), acc[a][b], 0, 0, 0);
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f1[4 + a]), __builtin_bit_cast(bf16x8, f1[b]), acc[a][b], 0, 0, 0);
+    }
+#endif
+}
+
 template <bool OP, int NST>
 __global__ __launch_bounds__(256, 1) void igemm4p_kernel(const IgemmParams p, const void* __restrict__ g_a, unsigned a_bytes,
                                                          const void* __restrict__ g_whi, const void* __restrict__ g_wlo, unsigned w_bytes,
                                                          const float* __restrict__ g_bias, const float* __restrict__ g_addend,
                                                          const float* __restrict__ g_mask, float* __restrict__ g_out, uint2* __restrict__ g_ohi,
                                                          uint2* __restrict__ g_olo, int w_rows, int w_ld8, int splits, float* __restrict__ g_ws,
-                                                         int n_items) {
+                                                         int n_items, int k_q, int k_r) {
   constexpr int TM = 2, TN = 2, BM = 128, BN = 128, BK = 32, NO = BK / 8, ES = 4;
   constexpr int A_U4 = 8 * BM, B_U4 = 2 * NO * BN, STAGE = A_U4 + B_U4;  // 16 KB + 16 KB
   constexpr int PER_STEP = 8;                                              // LDS-DMA instructions per wave and step: 4 gathered + 2 x 2 weight
@@ -58,7 +140,6 @@ __global__ __launch_bounds__(256, 1) void igemm4p_kernel(const IgemmParams p, co
   const int wm = wave >> 1, wn = wave & 1;
   const int il = lane & 31, h = lane >> 5;
   const int grid = (int)gridDim.x, bid = (int)blockIdx.x;
-  const int all_steps = p.Cred / BK;
 
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_a), 0, a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_whi), 0, w_bytes, 0x00020000);
@@ -86,10 +167,12 @@ __global__ __launch_bounds__(256, 1) void igemm4p_kernel(const IgemmParams p, co
       b_off[0] = b_off[1] = PP_BUF_OOB;
       return;
     }
-    const int split = it % splits, lb = it / splits;
-    const int tile_n = lb % p.n_tiles_n, tile_m = lb / p.n_tiles_n;
-    iss_k0 = (int)((long long)all_steps * split / splits);
-    iss_n = (int)((long long)all_steps * (split + 1) / splits) - iss_k0;
+    // (a 32-bit division by a run-time value is VALU work even for uniform operands: without the readfirstlane the quotients --
+    // and everything derived from them, the DMA's scalar offset included -- live in VGPRs and every LDS-DMA gets a waterfall loop)
+    const int lb = __builtin_amdgcn_readfirstlane(it / splits), split = it - lb * splits;
+    const int tile_m = __builtin_amdgcn_readfirstlane(lb / p.n_tiles_n), tile_n = lb - tile_m * p.n_tiles_n;
+    iss_k0 = split * k_q + (split < k_r ? split : k_r);  // the reduction's steps dealt out evenly: all_steps = splits * k_q + k_r
+    iss_n = k_q + (split < k_r ? 1 : 0);
     // gathered tile: one instruction = 8 rows x 8 pieces (the 128 contiguous bytes [hi0 lo0 .. hi3 lo3] of a row's 32-channel chunk);
     // wave w owns rows 32 w .. 32 w + 31; the lane at LDS piece position q of row r fetches piece q ^ ((r / 2) mod 8)
 #pragma unroll
@@ -128,16 +211,31 @@ __global__ __launch_bounds__(256, 1) void igemm4p_kernel(const IgemmParams p, co
   auto setup_consume = [&]() __attribute__((always_inline)) -> bool {
     const int it = item_of(con_round);
     if (it < 0) return false;
-    split = it % splits;
-    const int lb = it / splits;
-    n0 = (lb % p.n_tiles_n) * BN;
-    m0 = (lb / p.n_tiles_n) * BM;
-    const int k0 = (int)((long long)all_steps * split / splits);
-    con_n = (int)((long long)all_steps * (split + 1) / splits) - k0;
+    const int lb = __builtin_amdgcn_readfirstlane(it / splits);
+    split = it - lb * splits;
+    const int tile_m = __builtin_amdgcn_readfirstlane(lb / p.n_tiles_n);
+    n0 = (lb - tile_m * p.n_tiles_n) * BN;
+    m0 = tile_m * BM;
+    con_n = k_q + (split < k_r ? 1 : 0);
     con_j = 0;
     return true;
   };
   if (!setup_consume()) return;  // (workgroup-uniform, before any barrier)
+
+  // this lane's fragment offsets inside a stage (bytes; planes_fmt.h LAY 1): [half-step s][32-row block]
+  unsigned fa_hi[2][2], fa_lo[2][2], fb_hi[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int sa = pf_slot_a<BM, 1>(wm * 32 * TM + il + i * 32, 2 * s + h);
+      fa_hi[s][i] = 16u * (unsigned)sa;
+      fa_lo[s][i] = 16u * (unsigned)(sa ^ 1);
+      fb_hi[s][i] = 16u * (unsigned)pf_slot_b<BN, 1>(wn * 32 * TN + il + i * 32, 2 * s + h);
+    }
+  auto lds_addr = [&](const uint4* q) __attribute__((always_inline)) -> unsigned {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) uint4*)q;
+  };
 
   floatx16 acc[TM][TN];
   auto zero_acc = [&]() __attribute__((always_inline)) {
@@ -179,8 +277,7 @@ __global__ __launch_bounds__(256, 1) void igemm4p_kernel(const IgemmParams p, co
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     issue_one(stg(std::integral_constant<int, (U + NST - 1) % NST>{}));
-    const uint4* const A = stg(std::integral_constant<int, U>{});
-    mma_step<TM, TN, BM, BN, 0, 1>(acc, A, A, A + A_U4, A + A_U4 + NO * BN, wm * 32 * TM + il, wn * 32 * TN + il, h);
+    mma_step_asm(acc, lds_addr(stg(std::integral_constant<int, U>{})), fa_hi, fa_lo, fb_hi);
     if (++con_j == con_n) {
       finish_item();
       ++con_round;
@@ -220,7 +317,7 @@ void PP_API(pp4_launch_igemm4p)(hipStream_t st, IgemmParams& p, const void* ahi,
   auto go = [&](auto opc, auto nstc) {
     hipLaunchKernelGGL((igemm4p_kernel<decltype(opc)::value, decltype(nstc)::value>), dim3((unsigned)grid), dim3(256), 0, st, p, ahi, (unsigned)a_bytes, whi,
                        wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)(op ? ohi : nullptr), (uint2*)(op ? olo : nullptr), w_rows, w_ld8,
-                       splits, ws, n_items);
+                       splits, ws, n_items, (p.Cred / 32) / splits, (p.Cred / 32) % splits);
   };
   if (op) {
     if (nst == 3) go(std::true_type{}, std::integral_constant<int, 3>{});

@@ -66,6 +66,7 @@ def main():
                     help="plane format / arithmetic of the *3* modes: 0 = bf16 pairs (bf16x3), 1 = P16 (f16c8)")
     ap.add_argument("--ab", default="", help="ENV=a,b[,c]: time every mode once per value of an environment switch that the library reads "
                     "at every launch (PP_CONV3_DMA, PP_CONV3_DMA2, PP_CONV4P, PP_CONV4P_NST, PP_WGRAD4): interleaved rounds in ONE process")
+    ap.add_argument("--no-blocker", action="store_true", help="do not queue the timed launches behind a spinning kernel (round 1-3 behaviour)")
     ap.add_argument("--rounds", type=int, default=3, help="with --ab: rounds over the values (the fastest round of each is printed too)")
     args = ap.parse_args()
     ctx = ops.Context(0)
@@ -156,6 +157,10 @@ def main():
                     fn()
                 torch.cuda.synchronize()
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                # a launch through ctypes costs the host 20-30 us: behind a spinning kernel the host runs ahead, and the events
+                # bracket back-to-back GPU work (without it every launch under ~30 us measures the host, not the kernel)
+                if not args.no_blocker:
+                    torch.cuda._sleep(int(2.0e6 * (1 + args.iters * 0.04)))
                 s.record()
                 for _ in range(args.iters):
                     fn()
