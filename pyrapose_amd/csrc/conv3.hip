@@ -1957,18 +1957,6 @@ namespace {
 // 16-dword bank windows: conflict free.  Split over pixel ranges + f32 atomics like wgrad_kernel (conv.hip).
 typedef short shortx4 __attribute__((ext_vector_type(4)));
 
-struct Wgrad3Params {
-  int ld_src, ld_dy, ld_w;
-  int M, n_seg;
-  SegGeo seg[PP_MAX_SEG];
-  int Cin, Cout;
-  int kh, kw, stride, pad_t, pad_l;
-  int k_tiles_per_tap, n_tiles_k, n_tiles_n, splits, rows_per_split;
-  int max_wraps;  // ceil(32 / narrowest level width): row wraps one 32-row step can cross
-  int sp_min_steps;  // SP: listed 32-row blocks one workgroup should at least reduce (fewer splits when the list is short)
-  long long src_rows;
-  const float* inv_scale;  // device scalar 2^-G (NULL: 1): dy travels multiplied by 2^G (pp_ctx_set_grad_scale), dW / dbias leave unscaled
-};
 
 template <int TM, int TN, bool AP>
 __global__ __launch_bounds__(256, (TM * TN == 4) ? 2 : 3) void wgrad3_kernel(const Wgrad3Params p, const float* __restrict__ g_src,
@@ -2621,6 +2609,24 @@ extern "C" int PP_API(pp_conv2d_nhwc_bwd_weight_bf16x3)(pp_ctx* ctx, const pp_co
   // (tools/sweep_wgrad.sh: the small 1x1 layers of res4 / res5 take ~35 us for ANY tile / split choice: ~19 latency-bound
   // steps of a lone workgroup per CU plus the f32 atomics of splits x |dW|.  Register double-buffering of the staged tiles
   // (loads two steps ahead) shortens such lone-workgroup launches by 10-20 % in isolation, but no measurable step time.)
+  {
+    // Round 4: 3x3 stride-1 "same" layers on plane-stored operands (heads, FPN, bottleneck 3x3) -> the tap-row-reuse kernel of
+    // conv4.hip (one staged tile pair per kernel ROW, 192 accumulators, double-buffered LDS); PP_WGRAD3R=0 (read per launch: tests
+    // compare the two kernels in one process) or the deterministic slices mode keep wgrad3f
+    const char* const e_r = getenv("PP_WGRAD3R");
+    static const bool det = []() { const char* e = getenv("PP_WGRAD3_DETERMINISTIC"); return e && e[0] == '1'; }();
+    // OPT-IN (PP_WGRAD3R=1): results agree with wgrad3f to f32 summation order, but the dense launches are 1.15-1.45x SLOWER and
+    // the listed-block ones equal (profiles/r04_wgrad_tap_row_reuse.txt: one wave per SIMD leaves the step's ~400 instructions and
+    // the load latency uncovered)
+    if (e_r && e_r[0] == '1' && planes && !(det && ctx->ws != nullptr) && (!lazy_in || skip_list)) {
+      static const int sp_steps = []() { const char* e = getenv("PP_WGRAD3_SP_STEPS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1; }();
+      p.sp_min_steps = sp_steps;
+      if (PP_API(pp4_launch_wgrad3r)(ctx->stream, p, x_hi, x_lo, dy_hi, dy_lo, dw, dbias, skip_list, ctx->n_cu > 0 ? ctx->n_cu : 256)) {
+        PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_weight_bf16x3");
+        return PP_OK;
+      }
+    }
+  }
   bool big_k = (d->cin % 128 == 0);
   bool big_n = ((d->cout + 127) / 128 * 128) <= ((d->cout + 63) / 64 * 64);
   if (const char* e = getenv("PP_WGRAD3_TILE")) {  // tuning hook: "1,1" / "1,2" / "2,1" / "2,2"

@@ -304,6 +304,422 @@ __global__ __launch_bounds__(256, 1) void igemm4p_kernel(const IgemmParams p, co
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the look-ahead batches of steps that never come: landed before the wave ends
 }
 
+// ============================================================================================================================
+// wgrad3r_kernel: the weight gradient of a 3x3 stride-1 "same" convolution with TAP-ROW REUSE (round 4).
+//   dW[ty][tx][ci][co] = sum_m x[m + (ty - 1) W + (tx - 1)][ci] * dy[m][co]        (rows of one image row only: edges are padding)
+// wgrad3f stages a 32-pixel x tile and a 32-pixel dy tile per TAP: per 32-pixel step and wave 32 transposing reads + 8
+// ds_write_b128 for 12 MFMAs -- LDS-bound in P16 (2 700 LDS cycles against 1 536 MFMA cycles per CU step, 42 % MFMA-busy,
+// profiles/r03_pmc_stalls_both_formats.txt).  For a fixed kernel row ty the x tile of tap tx is the tile of tx = 1 shifted by one
+// PIXEL, i.e. by one row of the pixel-major LDS image, and dy is the same: one staged pair (34 x rows, 32 dy rows) serves the
+// three taps -- a third of the global loads and LDS stores per MFMA, and the dy fragments are read once per step.
+//  * 3 taps x (64 x 64 wave tile) = 192 accumulator registers per lane; with the staging registers and fragments ~300: ONE wave per
+//    SIMD (the 2-waves-per-SIMD form VERDICT r03 sketched would have 256 registers in all: 192 + fragments + addresses do not fit).
+//    With one wave per SIMD nothing else covers an LDS-DMA's 60-185 cycles of issue (the lesson of igemm4p above), so the operands
+//    are register-staged: plain buffer loads one step ahead, ds_write_b128 into the OTHER of two LDS buffers under the MFMAs of
+//    the current step, one barrier per step.
+//  * a pixel at the left (right) end of an image row has no tx = 0 (tx = 2) neighbour: the shifted tile holds the previous
+//    (next) image row's pixel there.  The 8 pixels of a fragment are 8 x 16 bits of its registers: the fragment is AND-ed with a
+//    mask built from two 32-bit words per step (bit p = pixel m + p is at the left / right edge; wave-uniform scalar arithmetic).
+//    Rows above / below the image (ty != 1) are out-of-range offsets of the staged x row: zeros.
+//  * grid = (kernel row ty) x (128-channel cin tiles) x (128-channel cout tiles) x row splits; f32 atomics into dW like wgrad3f.
+//  * SP: the reduction walks the listed 32-row blocks of dy (pp_row_block_list), like wgrad3f<.., SP>.
+// Conditions (host-checked): plane-stored operands, 3x3 / stride 1 / pad 1 on an unchanged grid, cin % 128 == 0, every level's row
+// count a multiple of 32 (a step never straddles two levels), narrowest level >= 12 pixels wide.
+__device__ __forceinline__ void and4(uint4& v, const unsigned (&m)[4]) {
+  v.x &= m[0]; v.y &= m[1]; v.z &= m[2]; v.w &= m[3];
+}
+
+template <bool SP>
+__global__ __launch_bounds__(256, 1) void wgrad3r_kernel(const Wgrad3Params p, const void* __restrict__ g_x0, const void* __restrict__ g_x1,
+                                                         unsigned x_bytes, const void* __restrict__ g_d0, const void* __restrict__ g_d1,
+                                                         unsigned d_bytes, float* __restrict__ g_dw, float* __restrict__ g_dbias,
+                                                         const int* __restrict__ g_list) {
+  constexpr int TM = 2, TN = 2, BM = 128, BN = 128, BK = 32;
+  // x rows per buffer: 34 are read; rows 32 .. 63 exist so that EVERY thread can store its "extra row" registers (zeros but for the
+  // threads of rows 0, 1) without a branch -- the loop body stays one basic block that the scheduler can interleave under the MFMAs
+  constexpr int XR = 2 * BK;
+  constexpr int PA = BM + 32, PB = BN + 32;  // LDS pitches in 16-bit elements (row + 64 bytes: conflict-free transposing reads)
+  constexpr int XB = XR * PA, GB = BK * PB;  // elements per plane and buffer
+  constexpr int BUF = 2 * XB + 2 * GB;
+  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BUF];  // 2 x 61 440 bytes
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float inv_g = p.inv_scale ? *p.inv_scale : 1.f;
+  const int wm = wave >> 1, wn = wave & 1;
+  int b = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int tile_n = b % p.n_tiles_n;
+  b /= p.n_tiles_n;
+  const int tile_k = b % p.n_tiles_k;
+  const int split = b / p.n_tiles_k;
+  const int ty = tile_k / p.k_tiles_per_tap;
+  const int ci0 = (tile_k - ty * p.k_tiles_per_tap) * BM;
+  const int n0 = tile_n * BN;
+  // (dense: the splits cut the PADDED position space, see below; rows_per_split counts positions)
+  int m_begin = split * p.rows_per_split;
+  int m_end = min(SP ? p.M : p.Mp, m_begin + p.rows_per_split);
+  int n_steps = (m_end - m_begin + BK - 1) / BK;
+  int s_idx = 0, s_end = 0;
+  const int blk_past = (p.M + BK - 1) / BK;
+  if (SP) {  // (see wgrad3f_kernel: a short list is shared by fewer splits)
+    const int n_act = g_list[0];
+    int s_eff = (n_act + p.sp_min_steps - 1) / p.sp_min_steps;
+    s_eff = s_eff < 1 ? 1 : (s_eff > p.splits ? p.splits : s_eff);
+    if (split >= s_eff) return;
+    s_idx = (int)((long long)n_act * split / s_eff);
+    s_end = (int)((long long)n_act * (split + 1) / s_eff);
+    n_steps = s_end - s_idx;
+    m_begin = (n_steps > 0 ? g_list[1 + s_idx] : blk_past) * BK;
+    m_end = p.M;
+  }
+
+  const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_x0), 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_x1), 0, x_bytes - 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_d0), 0, d_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_d1), 0, d_bytes - 16, 0x00020000);
+
+  // staging: 8 threads per row, thread q8 moves the 8-channel groups q8 and q8 + 8 (16 bytes of hi + 16 bytes of lo each)
+  const int prow = tid >> 3, q8 = tid & 7;
+  uint4 rx[2], rxl[2], re[2], rel[2], rd[2], rdl[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) re[j] = rel[j] = make_uint4(0u, 0u, 0u, 0u);
+  float4 bsum[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bsum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool do_bias = (g_dbias != nullptr) && (tile_k == 0);
+
+  // ---- the reduction space ----
+  // SP (listed blocks): the pixels themselves; the fragments of the edge taps are masked (edge words, below).
+  // Dense (PADK): the pixels with ONE PAD POSITION behind every image row (row length W + 1): a pad is an out-of-range offset for
+  // both operands -- zeros in the x tile and in the dy tile --, so the neighbour of a row's first (last) pixel at tap tx = 0 (2)
+  // IS a zero and no fragment needs masking (150 VALU per step less: with ONE wave per SIMD the step is bound by the instructions
+  // that wave has to issue, not by the matrix pipe); costs 1 / W more steps (1.3 % at 80 pixels, 5 % at 20).
+  // Thread `prow` stages position q = m_cur + prow: dy row prow and x row prow + 1; the threads of rows 0 / 1 also stage x row 0
+  // (position m_cur - 1) / x row 33 (position m_cur + 32).
+  constexpr bool PADK = !SP;
+  int d_OW, d_OH, d_xx, d_y, d_img;
+  bool d_ok;
+  auto decode = [&](int q) __attribute__((always_inline)) {  // branch-free (fixed trip count, selects): part of the loop's one basic block
+    int qbeg = PADK ? p.pos_begin[0] : p.seg[0].row_begin, rbeg = p.seg[0].row_begin;
+    d_OH = p.seg[0].OH; d_OW = p.seg[0].OW;
+#pragma unroll
+    for (int s = 1; s < PP_MAX_SEG; ++s) {
+      const int sb = PADK ? p.pos_begin[s] : p.seg[s].row_begin;
+      const bool in = s < p.n_seg && q >= sb;
+      qbeg = in ? sb : qbeg;
+      rbeg = in ? p.seg[s].row_begin : rbeg;
+      d_OH = in ? p.seg[s].OH : d_OH;
+      d_OW = in ? p.seg[s].OW : d_OW;
+    }
+    const int q_end = PADK ? p.Mp : p.M;
+    const int qc = q < 0 ? 0 : (q < q_end ? q : q_end - 1);
+    const int w1 = d_OW + (PADK ? 1 : 0), hw1 = d_OH * w1;
+    int rem;
+    const int n = div_small(qc - qbeg, hw1, __frcp_rn((float)hw1), &rem);
+    d_y = div_small(rem, w1, __frcp_rn((float)w1), &d_xx);
+    d_img = rbeg + n * d_OH * d_OW;  // first pixel of the image ("same" geometry: x and dy share the row space)
+    d_ok = q >= 0 && q < q_end && d_xx < d_OW;
+  };
+  int q_next = blk_past;
+  if (SP) q_next = (s_idx + 1 < s_end) ? g_list[1 + s_idx + 1] : blk_past;
+  int m_cur = m_begin;  // first position of the step being PREPARED (uniform)
+
+  // the edge words of the step at m_cur (SP; wave-uniform): bit j of .x / .y = pixel m_cur + j sits at x == 0 / x == W - 1.
+  // Lane 0 of wave w has decoded pixel m_cur + 8 w (same level: a listed block never straddles two levels, host-checked)
+  auto edge_bits = [&]() __attribute__((always_inline)) -> uint2 {
+    const int W = __builtin_amdgcn_readfirstlane(d_OW);
+    int x0 = __builtin_amdgcn_readfirstlane(d_xx) - 8 * wave;
+    x0 += x0 < 0 ? W : 0;
+    x0 += x0 < 0 ? W : 0;
+    x0 += x0 < 0 ? W : 0;
+    unsigned l = 0, r = 0;
+    int pl = x0 == 0 ? 0 : W - x0, pr = W - 1 - x0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      l |= pl < 32 ? (1u << pl) : 0u;
+      r |= pr < 32 ? (1u << pr) : 0u;
+      pl += W;
+      pr += W;
+    }
+    return make_uint2(l, r);
+  };
+
+  // Software pipeline over THREE steps: prep() -- positions, offsets, edge words of step s + 2 (VALU / SALU only) -- runs in the
+  // shadow of the MFMAs of step s; issue() -- the 12 buffer loads of step s + 1, offsets already in registers -- sits at the very
+  // top of the step (pinned by a sched_barrier: left alone the scheduler sinks the loads to the ds_writes that need them, and
+  // every step pays a global-load latency).
+  int o_x = PP_BUF_OOB, o_e = PP_BUF_OOB, o_d[2] = {PP_BUF_OOB, PP_BUF_OOB};
+  auto x_off = [&]() __attribute__((always_inline)) -> int {  // byte offset of the x pixel of the decoded position at kernel row ty, or out of range
+    const int sy = d_y + ty - 1;
+    const int o = ((d_img + sy * d_OW + d_xx) * p.ld_src + ci0) * 4 + 32 * q8;
+    return o | ((d_ok && (unsigned)sy < (unsigned)d_OH) ? 0 : PP_BUF_OOB);  // (bit 31 = out of range; no select of the offset: see prep())
+  };
+  auto prep = [&]() __attribute__((always_inline)) -> uint2 {
+    const int q = m_cur + prow;
+    decode(q);
+    uint2 eb = make_uint2(0u, 0u);
+    if (SP) eb = edge_bits();
+    o_x = x_off();
+    const int dyo = ((d_img + d_y * d_OW + d_xx) * p.ld_dy + n0) * 4 + 32 * q8;
+    const bool in_rng = d_ok && q < m_end;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) o_d[j] = dyo | ((in_rng && (n0 + 8 * (q8 + 8 * j) < p.ld_dy)) ? 0 : PP_BUF_OOB);
+    decode(prow == 0 ? m_cur - 1 : m_cur + BK);
+    // (the other threads fetch nothing -- an offset with bit 31 set is out of range: zeros, stored into rows that are never read.  The
+    // OR keeps the decode above unconditional: behind a select the compiler wraps it in an exec-masked branch, which cuts the step's
+    // basic block in two and leaves this whole address computation OUTSIDE the MFMAs' shadow)
+    o_e = x_off() | (prow < 2 ? 0 : PP_BUF_OOB);
+    if (SP) {
+      ++s_idx;
+      m_cur = q_next * BK;
+      q_next = (s_idx + 1 < s_end) ? g_list[1 + s_idx + 1] : blk_past;
+    } else {
+      m_cur += BK;
+    }
+    return eb;
+  };
+  auto issue = [&]() __attribute__((always_inline)) {
+#if defined(PP_ABL) && PP_ABL == 1  // ablation: no global loads
+    return;
+#endif
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      rx[j] = buf_load16(rs_x0, o_x, 256 * j);
+      rxl[j] = buf_load16(rs_x1, o_x, 256 * j);
+      rd[j] = buf_load16(rs_d0, o_d[j], 256 * j);
+      rdl[j] = buf_load16(rs_d1, o_d[j], 256 * j);
+      re[j] = buf_load16(rs_x0, o_e, 256 * j);
+      rel[j] = buf_load16(rs_x1, o_e, 256 * j);
+    }
+  };
+  auto bias_step = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned hw4[4] = {rd[j].x, rd[j].y, rd[j].z, rd[j].w}, lw4[4] = {rdl[j].x, rdl[j].y, rdl[j].z, rdl[j].w};
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) fmt_value2(hw4[e], lw4[e], &v[2 * e], &v[2 * e + 1]);
+      bsum[2 * j].x += v[0]; bsum[2 * j].y += v[1]; bsum[2 * j].z += v[2]; bsum[2 * j].w += v[3];
+      bsum[2 * j + 1].x += v[4]; bsum[2 * j + 1].y += v[5]; bsum[2 * j + 1].z += v[6]; bsum[2 * j + 1].w += v[7];
+    }
+  };
+  auto store_step = [&](unsigned short* buf) __attribute__((always_inline)) {
+#if defined(PP_ABL) && PP_ABL == 3  // ablation: no LDS stores (keep the loaded registers alive)
+    {
+      unsigned k = 0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) k ^= rx[j].x ^ rx[j].w ^ rxl[j].x ^ rxl[j].w ^ rd[j].x ^ rd[j].w ^ rdl[j].x ^ rdl[j].w ^ re[j].x ^ re[j].w ^ rel[j].x ^ rel[j].w;
+      asm volatile("" ::"v"(k));
+    }
+    return;
+#endif
+    unsigned short* const Xhi = buf;
+    unsigned short* const Xlo = buf + XB;
+    unsigned short* const Ghi = buf + 2 * XB;
+    unsigned short* const Glo = Ghi + GB;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = 8 * (q8 + 8 * j);
+      *reinterpret_cast<uint4*>(Xhi + (prow + 1) * PA + col) = rx[j];
+      *reinterpret_cast<uint4*>(Xlo + (prow + 1) * PA + col) = rxl[j];
+      uint4 gl = rdl[j];
+#if PP_FMT == 1
+      // dy's lo units with their bytes swapped once, here, instead of in every fragment of every tap (see wgrad_step)
+      gl.x = __builtin_amdgcn_perm(gl.x, gl.x, 0x02030001u); gl.y = __builtin_amdgcn_perm(gl.y, gl.y, 0x02030001u);
+      gl.z = __builtin_amdgcn_perm(gl.z, gl.z, 0x02030001u); gl.w = __builtin_amdgcn_perm(gl.w, gl.w, 0x02030001u);
+#endif
+      *reinterpret_cast<uint4*>(Ghi + prow * PB + col) = rd[j];
+      *reinterpret_cast<uint4*>(Glo + prow * PB + col) = gl;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = 8 * (q8 + 8 * j);
+      const int er = prow == 0 ? 0 : BK + prow;  // thread row 0 -> x row 0, thread row 1 -> x row 33, the others -> rows nobody reads
+      *reinterpret_cast<uint4*>(Xhi + er * PA + col) = re[j];
+      *reinterpret_cast<uint4*>(Xlo + er * PA + col) = rel[j];
+    }
+  };
+
+  floatx16 acc[3][TM][TN];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int c = 0; c < TN; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][a][c][r] = 0.f;
+
+  // transposed-read lane roles (16-lane groups): group g -> columns 16 (g & 1) .., pixel half hh = g >> 1 (see wgrad3f_kernel)
+  const int grp = lane >> 4, gi = lane & 15, gq = gi >> 2, gp = gi & 3;
+  const int cbase = 16 * (grp & 1), hh = grp >> 1;
+  const int il = lane & 31, h = lane >> 5;
+  const int xcol0 = wm * 32 * TM + cbase + 4 * gp, gcol0 = wn * 32 * TN + cbase + 4 * gp;
+
+  // 8 pixels of a fragment (bits 8 hh + 16 s .. + 7 of an edge word, 1 = at the edge) -> the four dwords that keep the others
+  auto frag_mask = [&](unsigned bits, int s, unsigned (&m)[4]) __attribute__((always_inline)) {
+    const unsigned b8 = ~(bits >> (16 * s + 8 * hh));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned lo = (unsigned)__builtin_amdgcn_sbfe((int)b8, 2 * i, 1), hi = (unsigned)__builtin_amdgcn_sbfe((int)b8, 2 * i + 1, 1);
+      m[i] = (lo & 0xffffu) | (hi & 0xffff0000u);
+    }
+  };
+
+  auto compute = [&](const unsigned short* buf, uint2 eb) __attribute__((always_inline)) {
+#if defined(PP_ABL) && PP_ABL == 2  // ablation: no fragment reads, no MFMAs
+    return;
+#endif
+    const unsigned short* const Xhi = buf;
+    const unsigned short* const Xlo = buf + XB;
+    const unsigned short* const Ghi = buf + 2 * XB;
+    const unsigned short* const Glo = Ghi + GB;
+    unsigned ml[2][4], mr[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      frag_mask(eb.x, s, ml[s]);
+      frag_mask(eb.y, s, mr[s]);
+    }
+    // x row of dy pixel k at tap tx: k + tx (LDS x row 0 = pixel m - 1)
+    auto xfrag = [&](const unsigned short* X, int s, int a, int tx) __attribute__((always_inline)) -> uint4 {
+      const int row0 = 16 * s + 8 * hh + gq + tx, col = xcol0 + a * 32;
+      const bf16x8 t = tr_frag(X, row0 * PA + col, (row0 + 4) * PA + col);
+      uint4 u = *reinterpret_cast<const uint4*>(&t);
+      if (SP && tx == 0) and4(u, ml[s]);
+      if (SP && tx == 2) and4(u, mr[s]);
+      return u;
+    };
+    auto gfrag = [&](const unsigned short* G, int s, int c) __attribute__((always_inline)) -> uint4 {
+      const int row0 = 16 * s + 8 * hh + gq, col = gcol0 + c * 32;
+      const bf16x8 t = tr_frag(G, row0 * PB + col, (row0 + 4) * PB + col);
+      return *reinterpret_cast<const uint4*>(&t);
+    };
+#if PP_FMT == 1
+    intx8 gq8[TN];
+    uint4 gh[2][TN];
+#pragma unroll
+    for (int c = 0; c < TN; ++c) {
+      const uint4 u0 = gfrag(Glo, 0, c), u1 = gfrag(Glo, 1, c);
+      gq8[c][0] = (int)u0.x; gq8[c][1] = (int)u0.y; gq8[c][2] = (int)u0.z; gq8[c][3] = (int)u0.w;
+      gq8[c][4] = (int)u1.x; gq8[c][5] = (int)u1.y; gq8[c][6] = (int)u1.z; gq8[c][7] = (int)u1.w;
+      gh[0][c] = gfrag(Ghi, 0, c);
+      gh[1][c] = gfrag(Ghi, 1, c);
+    }
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const uint4 u0 = xfrag(Xlo, 0, a, tx), u1 = xfrag(Xlo, 1, a, tx);
+        intx8 xq8;
+        xq8[0] = (int)u0.x; xq8[1] = (int)u0.y; xq8[2] = (int)u0.z; xq8[3] = (int)u0.w;
+        xq8[4] = (int)u1.x; xq8[5] = (int)u1.y; xq8[6] = (int)u1.z; xq8[7] = (int)u1.w;
+#pragma unroll
+        for (int c = 0; c < TN; ++c)
+          acc[tx][a][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xq8, gq8[c], acc[tx][a][c], 1, 1, 0, P16_SCALES, 1, P16_SCALES);
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+          const uint4 u = xfrag(Xhi, s, a, tx);
+          const halfx8 xh = *reinterpret_cast<const halfx8*>(&u);
+#pragma unroll
+          for (int c = 0; c < TN; ++c)
+            acc[tx][a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, *reinterpret_cast<const halfx8*>(&gh[s][c]), acc[tx][a][c], 0, 0, 0);
+        }
+    }
+#else
+    uint4 gh[2][TN], gl[2][TN];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int c = 0; c < TN; ++c) {
+        gh[s][c] = gfrag(Ghi, s, c);
+        gl[s][c] = gfrag(Glo, s, c);
+      }
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+          const uint4 uh = xfrag(Xhi, s, a, tx), ul = xfrag(Xlo, s, a, tx);
+          const bf16x8 xh = *reinterpret_cast<const bf16x8*>(&uh), xl = *reinterpret_cast<const bf16x8*>(&ul);
+#pragma unroll
+          for (int c = 0; c < TN; ++c) {
+            acc[tx][a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, *reinterpret_cast<const bf16x8*>(&gh[s][c]), acc[tx][a][c], 0, 0, 0);
+            acc[tx][a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, *reinterpret_cast<const bf16x8*>(&gl[s][c]), acc[tx][a][c], 0, 0, 0);
+            acc[tx][a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, *reinterpret_cast<const bf16x8*>(&gh[s][c]), acc[tx][a][c], 0, 0, 0);
+          }
+        }
+#endif
+  };
+
+  auto k_loop = [&](auto with_bias) __attribute__((always_inline)) {
+    constexpr bool WB = decltype(with_bias)::value;
+    uint2 eb0 = prep();  // step 0
+    issue();
+    uint2 eb1 = prep();  // step 1
+    if (WB) bias_step();
+    store_step(smem);
+    __syncthreads();
+    for (int step = 0; step < n_steps; ++step) {
+      issue();  // step + 1 (past the last step every dy row is out of range: zeros, stored and never multiplied)
+      __builtin_amdgcn_sched_barrier(0);
+      const uint2 eb2 = prep();  // step + 2
+      compute(smem + (step & 1) * BUF, eb0);
+      // the order inside the step: left alone the scheduler emits all of prep() (~200 VALU / SALU) and THEN the MFMAs; pipeline
+      // them instead -- the first fragments, then per MFMA two transposing reads and six scalar / vector instructions
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int i = 0; i < 36; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (WB) bias_step();
+      store_step(smem + ((step + 1) & 1) * BUF);
+      __syncthreads();
+      eb0 = eb1;
+      eb1 = eb2;
+    }
+  };
+  if (do_bias) k_loop(std::true_type{});
+  else k_loop(std::false_type{});
+
+  // reduction over the row splits: f32 atomics into dW (fire and forget; see wgrad3f_kernel)
+#pragma unroll
+  for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + wm * 32 * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const long long row = (long long)((ty * 3 + tx) * p.Cin + ci) * p.ld_w;
+#pragma unroll
+        for (int c = 0; c < TN; ++c) {
+          const int co = n0 + wn * 32 * TN + c * 32 + il;
+          if (co < p.Cout) atomicAdd(g_dw + row + co, acc[tx][a][c][r] * inv_g);
+        }
+      }
+  if (do_bias) {
+    float* red = reinterpret_cast<float*>(smem);  // [32][BN] floats
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      *reinterpret_cast<float4*>(red + prow * BN + 8 * (q8 + 8 * j)) = bsum[2 * j];
+      *reinterpret_cast<float4*>(red + prow * BN + 8 * (q8 + 8 * j) + 4) = bsum[2 * j + 1];
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) s += red[r * BN + tid];
+      if (n0 + tid < p.Cout) atomicAdd(g_dbias + n0 + tid, s * inv_g);
+    }
+  }
+}
+
 }  // namespace
 
 void PP_API(pp4_launch_igemm4p)(hipStream_t st, IgemmParams& p, const void* ahi, const void* whi, const void* wlo, int w_rows, int w_ld8,
@@ -326,4 +742,65 @@ void PP_API(pp4_launch_igemm4p)(hipStream_t st, IgemmParams& p, const void* ahi,
     if (nst == 3) go(std::false_type{}, std::integral_constant<int, 3>{});
     else go(std::false_type{}, std::integral_constant<int, 4>{});
   }
+}
+
+// the tap-row-reuse weight gradient (wgrad3r_kernel); returns false when the launch does not meet its conditions (the caller then
+// takes wgrad3f).  list: the listed 32-row blocks of dy (pp_row_block_list) or NULL.
+bool PP_API(pp4_launch_wgrad3r)(hipStream_t st, Wgrad3Params& p, const void* xhi, const void* xlo, const void* dhi, const void* dlo, float* dw,
+                                float* dbias, const int* list, int n_cu) {
+  if (!(p.kh == 3 && p.kw == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && p.Cin % 128 == 0 && xhi && dhi)) return false;
+  int min_ow = 1 << 30;
+  long long pos = 0;
+  for (int i = 0; i < p.n_seg; ++i) {
+    if (p.seg[i].OH != p.seg[i].SH || p.seg[i].OW != p.seg[i].SW || p.seg[i].row_begin != p.seg[i].src_row_begin) return false;
+    if (list && i + 1 < p.n_seg && p.seg[i + 1].row_begin % 32 != 0) return false;  // (a listed 32-row block never straddles two levels)
+    min_ow = p.seg[i].OW < min_ow ? p.seg[i].OW : min_ow;
+    // the dense reduction walks positions: every image row followed by one pad
+    const long long rows = (i + 1 < p.n_seg ? p.seg[i + 1].row_begin : p.M) - p.seg[i].row_begin;
+    p.pos_begin[i] = (int)pos;
+    pos += rows / p.seg[i].OW * (p.seg[i].OW + 1);
+  }
+  p.Mp = (int)pos;
+  const long long x_bytes = p.src_rows * (long long)p.ld_src * 4, d_bytes = (long long)p.M * p.ld_dy * 4;
+  if (!(min_ow >= (list ? 12 : 2) && x_bytes < (1ll << 31) && d_bytes < (1ll << 31) && pos < (1 << 24) && p.src_rows > 0)) return false;
+  p.k_tiles_per_tap = p.Cin / 128;
+  p.n_tiles_k = 3 * p.k_tiles_per_tap;
+  p.n_tiles_n = (p.Cout + 127) / 128;
+  const int tiles = p.n_tiles_k * p.n_tiles_n;
+  const int R = list ? p.M : p.Mp;  // length of the reduction space
+  // row splits: one workgroup per CU and ~1 us per 3-tap step; every split adds a |dW| of f32 atomics (~1.3 TB/s, about half of it
+  // under other workgroups' loops)
+  int max_splits = (R + 255) / 256;  // at least 8 steps per workgroup
+  if (max_splits > 128) max_splits = 128;
+  if (max_splits < 1) max_splits = 1;
+  const double atomic_steps_per_split = 0.5 * (double)tiles * 3.0 * 128.0 * 128.0 * 4.0 / 1.3e6 / 1.0;
+  int splits = 1;
+  double best = 1e300;
+  for (int sp = 1; sp <= max_splits; ++sp) {
+    const double steps = (double)((R + sp - 1) / sp + 31) / 32.0 + 6.0;
+    const double rounds = (double)(((long long)tiles * sp + n_cu - 1) / n_cu);
+    const double cost = rounds * steps + atomic_steps_per_split * sp;
+    if (cost < best * 0.995) {
+      best = cost;
+      splits = sp;
+    }
+  }
+  if (const char* e = getenv("PP_WGRAD3R_SPLITS")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= max_splits) splits = v;
+  }
+  int rps = (R + splits - 1) / splits;
+  rps = (rps + 31) / 32 * 32;
+  splits = (R + rps - 1) / rps;
+  p.splits = splits;
+  p.rows_per_split = rps;
+  if (p.sp_min_steps < 1) p.sp_min_steps = 1;
+  if (getenv("PP_CONV_DEBUG")) fprintf(stderr, "wgrad3r tiles %d (3 taps each) splits %d (M %d)%s\n", tiles, splits, p.M, list ? " listed blocks" : "");
+  if (list)
+    hipLaunchKernelGGL((wgrad3r_kernel<true>), dim3((unsigned)(tiles * splits)), dim3(256), 0, st, p, xhi, xlo, (unsigned)x_bytes, dhi, dlo,
+                       (unsigned)d_bytes, dw, dbias, list);
+  else
+    hipLaunchKernelGGL((wgrad3r_kernel<false>), dim3((unsigned)(tiles * splits)), dim3(256), 0, st, p, xhi, xlo, (unsigned)x_bytes, dhi, dlo,
+                       (unsigned)d_bytes, dw, dbias, (const int*)nullptr);
+  return true;
 }

@@ -51,6 +51,23 @@ struct IgemmParams {
                    // the remainder of a launch whose full rounds igemm4x_kernel took); split-K slices hold rows m_off .. M - 1
 };
 
+// the weight-gradient kernels (conv3.hip: wgrad3 / wgrad3f; conv4.hip: wgrad3r)
+struct Wgrad3Params {
+  int ld_src, ld_dy, ld_w;
+  int M, n_seg;
+  SegGeo seg[PP_MAX_SEG];
+  int Cin, Cout;
+  int kh, kw, stride, pad_t, pad_l;
+  int k_tiles_per_tap, n_tiles_k, n_tiles_n, splits, rows_per_split;
+  int max_wraps;  // ceil(32 / narrowest level width): row wraps one 32-row step can cross
+  int sp_min_steps;  // SP: listed 32-row blocks one workgroup should at least reduce (fewer splits when the list is short)
+  long long src_rows;
+  const float* inv_scale;  // device scalar 2^-G (NULL: 1): dy travels multiplied by 2^G (pp_ctx_set_grad_scale), dW / dbias leave unscaled
+  // wgrad3r (conv4.hip), dense reduction: the position space with one pad behind every image row -- first position of each level, total
+  int pos_begin[PP_MAX_SEG];
+  int Mp;
+};
+
 // Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8, each with a private L2).
 // Remap so that every XCD walks a CONTIGUOUS range of logical tiles: the N-tiles of one M-tile (same A
 // rows) and neighbouring M-tiles (overlapping 3x3 halos, same weight step) then share one L2.

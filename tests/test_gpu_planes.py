@@ -652,3 +652,66 @@ def test_persistent_1x1_gemm_matches_register_staged(ctx, monkeypatch, case):
         ref = (merged(gp).double() @ wv.t() + merged(ap).double()) * (xv > 0)
     err = (va.double() - ref).abs().max() / ref.abs().max()
     assert float(err) <= (1e-4 if FMT[0] == 1 else 3e-5), float(err)
+
+
+@pytest.mark.parametrize("case", ["heads3", "one_level_narrow", "cout144"])
+def test_tap_row_reuse_weight_gradient_matches_wgrad3f(ctx, monkeypatch, case):
+    """Round 4, wgrad3r_kernel (csrc/conv4.hip): the weight gradient of a 3x3 stride-1 'same' layer with one staged (x, dy) tile
+    pair per kernel ROW -- the three taps read the x tile at pixel offsets -1 / 0 / +1, edge pixels masked out of the fragments --
+    against wgrad3f (PP_WGRAD3R=0, read per launch): same products, another f32 summation order.  Dense and over a list of
+    32-row blocks; bias gradient; a three-level row space (levels change inside a split), a narrow single level (two image-row
+    wraps per step), a cout that leaves the second column tile mostly empty; and against float64."""
+    import torch.nn.functional as F
+    from pyrapose_amd import ops
+    rng = np.random.default_rng(47)
+    B, shapes, cin, cout = {"heads3": (2, [(32, 48), (16, 24), (8, 12)], 128, 256),
+                            "one_level_narrow": (3, [(20, 16)], 256, 128),
+                            "cout144": (1, [(32, 40)], 128, 144)}[case]
+    k = 3
+    rows = sum(B * h * w for h, w in shapes)
+    ld_y = (cout + 31) // 32 * 32
+    d = ops.make_conv_desc(B, shapes, shapes, cin, cout, k, 1, 1, 1, cin, ld_y, (cout + 15) // 16 * 16)
+    x = torch.as_tensor(rng.standard_normal((rows, cin)), dtype=torch.float32).cuda()
+    dy = torch.zeros((rows, ld_y), dtype=torch.float32, device="cuda")
+    dy[:, :cout] = torch.as_tensor(rng.standard_normal((rows, cout)), dtype=torch.float32).cuda()
+    # a sparse gradient: non-zero in a few runs of rows only
+    dys = torch.zeros_like(dy)
+    for a in rng.integers(0, rows - 40, size=6):
+        n = int(rng.integers(3, 40))
+        dys[a: a + n] = dy[a: a + n]
+    xp, gp, sp = split(ctx, x), split(ctx, dy), split(ctx, dys)
+    skip = ops.row_block_list(ctx, dys, cout)
+    ld_w = (cout + 15) // 16 * 16
+    out = {}
+    for r in ("0", "1"):
+        monkeypatch.setenv("PP_WGRAD3R", r)
+        dw, db = torch.zeros((k * k * cin, ld_w), device="cuda"), torch.zeros((ld_w,), device="cuda")
+        ops.conv_bwd_weight3(ctx, d, None, None, dw, db, x_planes=xp, dy_planes=gp)
+        dws, dbs = torch.zeros((k * k * cin, ld_w), device="cuda"), torch.zeros((ld_w,), device="cuda")
+        ops.conv_bwd_weight3(ctx, d, None, None, dws, dbs, x_planes=xp, dy_planes=sp, dy_skip=skip)
+        torch.cuda.synchronize()
+        out[r] = (dw, db, dws, dbs)
+    monkeypatch.delenv("PP_WGRAD3R", raising=False)
+    tol = 3e-5 if FMT[0] == 1 else 1e-5  # (two evaluations of one arithmetic: f32 summation order)
+    for i in range(4):
+        a, b_ = out["0"][i], out["1"][i]
+        assert float(b_.abs().max()) > 0
+        assert float((a - b_).abs().max()) <= tol * float(a.abs().max()), (i, float((a - b_).abs().max()), float(a.abs().max()))
+    assert float(out["1"][0][:, cout:].abs().max()) == 0 if ld_w > cout else True
+    # float64: dW[ty][tx] = sum over pixels of x[pixel + offset]^T dy[pixel], image by image and level by level
+    xv, gv = merged(xp).double(), merged(gp).double()[:, :cout]
+    ref = torch.zeros((k, k, cin, cout), dtype=torch.float64, device="cuda")
+    r0 = 0
+    for (h, w) in shapes:
+        n = B * h * w
+        xi = xv[r0: r0 + n].reshape(B, h, w, cin)
+        gi = gv[r0: r0 + n].reshape(B, h, w, cout)
+        xpad = F.pad(xi, (0, 0, 1, 1, 1, 1))
+        for ty in range(3):
+            for tx in range(3):
+                ref[ty, tx] += torch.einsum("bhwi,bhwo->io", xpad[:, ty: ty + h, tx: tx + w, :], gi)
+        r0 += n
+    got = out["1"][0][:, :cout].double().reshape(k, k, cin, cout)
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err <= (1e-4 if FMT[0] == 1 else 2e-5), err
+    assert float((out["1"][1][:cout].double() - gv.sum(0)).abs().max()) <= 1e-4 * float(gv.sum(0).abs().max())
