@@ -245,6 +245,13 @@ int pp_upsample_nearest_add_bwd_v(pp_ctx* ctx, int n_img, int sh, int sw, int th
                                   const pp_tview* base, const pp_tview* dsrc);
 /* planes -> float32 (value = hi + lo), n % 4 == 0: the inverse of pp_split_planes_bf16x3 up to 2^-17 */
 int pp_merge_planes_bf16x3(pp_ctx* ctx, size_t n, const void* hi, const void* lo, float* dst);
+/* Audit of a P16 tensor [rows][ld] (packed planes, columns < cols; ld, cols % 8 == 0; the context must be in plane format 1): ADDS to
+ * stats4_dev[0..3] (uint64, device) the elements looked at, the non-zero halves, the halves AT the encode's clamp (|h| >= 28 672) and
+ * the subnormal halves (0 < |h| < 2^-14).  within (may be NULL): uint8 flags of the 32-row blocks to look at.  The P16 encode clamps
+ * and a half underflows silently (csrc/p16.h); this is how a caller sees whether a step came near either end: Engine.p16_stats(),
+ * asserted in tests/test_gpu_parity.py, printed by bench.py.  No reference counterpart (the reference computes in float32). */
+int pp_planes_stats(pp_ctx* ctx, const void* hi, const void* lo, long long rows, int ld, int cols, const unsigned char* within,
+                    unsigned long long* stats4_dev);
 /* [n_img,h,w,3] -> [n_img,h,w,4] zero-padded channel (feeds conv1 as cin == 4) */
 int pp_pack_rgb_to_4(pp_ctx* ctx, size_t n_pixels, const float* x3, float* x4);
 /* utils/image.py:35-62 preprocess_image(mode='caffe') + preprocessing/generator.py:319-336 compute_inputs in one pass:

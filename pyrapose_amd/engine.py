@@ -381,6 +381,7 @@ class Engine(object):
                 self.ctxs[-1].set_workspace(ws_mb << 20)  # (same launch choices -- split-K at small sizes -- as on lane 0: same bits)
             self.prefix_lane = len(self.streams) - 1
         self.acts = OrderedDict()
+        self._plane_grads = []
         self.step_count = 0
         self._build_forward()
         self.levels = arch.level_shapes(self.H, self.W, arch.PYRAMID_LEVELS[pyramid])
@@ -836,7 +837,9 @@ class Engine(object):
     def _new_grad(self, rows, ld, fmt=0):
         """an uninitialised gradient matrix in the mode's storage format (fmt: the plane format of the tensor it belongs to)"""
         if self.po and ld % 8 == 0:
-            return Grad(None, _new_planes(rows, ld), fmt)
+            g = Grad(None, _new_planes(rows, ld), fmt)
+            self._plane_grads.append(g)  # (p16_stats() looks at the P16 ones after a step)
+            return g
         return Grad(torch.empty((rows, ld), dtype=torch.float32, device="cuda"))
 
     def _finalize(self, act, producer=None):
@@ -1325,6 +1328,33 @@ class Engine(object):
         self.params.import_trainable(self.params.v, state["v"])
         self.step_count = int(state["iterations"])
         torch.cuda.synchronize()
+
+    def p16_stats(self):
+        """Where the halves of this plan's P16 tensors sit in the format's range, after the last forward / train step
+        (pp_planes_stats): {'activations' | 'gradients': {'elements', 'nonzero', 'clamped', 'subnormal'}} plus 'grad_scale_log2'.
+        `clamped` counts halves AT the encode's clamp (|x| >= 28 672: the P16 encode saturates silently), `subnormal` non-zero
+        halves below 2^-14 (the element has lost significand bits; for gradients: the power-of-two scale 2^G is too small).  Lazily
+        filled sparse gradients are read inside their flagged blocks only.  An audit pass over HBM (~0.3 ms per GB): never timed."""
+        torch.cuda.synchronize()
+        ctx1 = self.ctx.twin(1)
+        out = {}
+        for kind, items in (("activations", [(a.pl, None) for a in self.acts.values() if a.pl is not None and a.fmt == 1]),
+                            ("gradients", [(g.pl, (g.within if g.lazy else None)) for g in self._plane_grads if g.pl is not None and g.fmt == 1])):
+            st = torch.zeros((4,), dtype=torch.int64, device="cuda")
+            spans = []  # byte ranges already counted (the pyramid levels are slices of one buffer: largest tensors first)
+            for pl, within in sorted(items, key=lambda it: -it[0][0].shape[0]):
+                ld = ops.planes_ld(pl)
+                a = pl[0].data_ptr()
+                b = a + pl[0].shape[0] * ld * 4
+                if pl[0].shape[0] == 0 or any(a >= lo and b <= hi for lo, hi in spans):
+                    continue
+                spans.append((a, b))
+                ops.planes_stats(ctx1, pl, ld, st, within)
+            v = st.cpu().numpy()
+            out[kind] = dict(elements=int(v[0]), nonzero=int(v[1]), clamped=int(v[2]), subnormal=int(v[3]))
+        if self.gscale is not None:
+            out["grad_scale_log2"] = float(torch.log2(self.gscale[0]).cpu())
+        return out
 
     def losses(self):
         v = self.loss_sums.detach().cpu().numpy()

@@ -288,6 +288,15 @@ def merge_planes3(ctx, planes, dst):
     check(lib.pp_merge_planes_bf16x3(ctx.handle, dst.numel(), _ptr(planes[0]), _ptr(planes[1]), _ptr(dst)), ctx.handle, "pp_merge_planes_bf16x3")
 
 
+def planes_stats(ctx, planes, cols, stats, within=None):
+    """pp_planes_stats: adds (elements, non-zero, at the clamp, subnormal) of a P16 tensor's halves to stats (int64 [4], device);
+    ctx must be the P16 twin; within = uint8 flags of the 32-row blocks to look at"""
+    hi, lo = planes
+    check(lib.pp_planes_stats(ctx.handle, _ptr(hi), _ptr(lo), int(hi.shape[0]), planes_ld(planes), int(cols), _ptr(within), _ptr(stats)), ctx.handle,
+          "pp_planes_stats")
+    return stats
+
+
 def positive_row_blocks(ctx, rs, n_anchor, y_true, flags):
     """pp_positive_row_blocks: flags[b] = 1 where the 32-row block b of the row space rs holds an anchor with state 1
     (y_true [B, N, stride], state = last column)"""

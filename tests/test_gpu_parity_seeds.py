@@ -27,5 +27,5 @@ def test_config1_train_step_other_seeds(ctx, k):
     B, H, W, C = 8, 480, 640, 13
     x, images, anns = bench.synth_batch(B, H, W, C, seed=2000 + 17 * k, boxes=(None, 1, 8, 15)[k % 4])
     tg = UA.anchor_targets_bbox_device(UA.anchors_for_shape_device((H, W)), images, anns, C)
-    w, worst, total = _train_step_vs_oracle(ctx, B, H, W, C, x, tg, arch.init_weights(C, seed=100 + k))
+    w, worst, total, _ = _train_step_vs_oracle(ctx, B, H, W, C, x, tg, arch.init_weights(C, seed=100 + k))
     assert max(w.values()) <= 1e-3 and worst[1] <= 1e-3
