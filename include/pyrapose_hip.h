@@ -195,6 +195,9 @@ int pp_convert_planes(pp_ctx* ctx, size_t n, const void* src_hi, const void* src
  * derives from them carries the same factor; pp_ctx_set_grad_scale (persistent; NULL = none) makes the weight-gradient launches of
  * this context multiply dW / dbias by scale2[1] when their operands are planes. */
 int pp_grad_scale_from_counts(pp_ctx* ctx, const int* counts_dev, int n_counts, float* scale2_dev);
+/* the same with G shifted by log2_adjust (-16 .. 16): a caller whose loss weights differ from the reference's defaults (losses.py:
+ * orthogonal_l1 weight 0.125, focal alpha 0.25) takes the headroom out of / puts it into the scale -- Engine: -ceil(log2(largest ratio)) */
+int pp_grad_scale_from_counts_adj(pp_ctx* ctx, const int* counts_dev, int n_counts, float* scale2_dev, int log2_adjust);
 int pp_split_planes_scaled_bf16x3(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo, const float* scale_dev);
 int pp_ctx_set_grad_scale(pp_ctx* ctx, const float* scale2_dev);
 
@@ -246,12 +249,12 @@ int pp_upsample_nearest_add_bwd_v(pp_ctx* ctx, int n_img, int sh, int sw, int th
 /* planes -> float32 (value = hi + lo), n % 4 == 0: the inverse of pp_split_planes_bf16x3 up to 2^-17 */
 int pp_merge_planes_bf16x3(pp_ctx* ctx, size_t n, const void* hi, const void* lo, float* dst);
 /* Audit of a P16 tensor [rows][ld] (packed planes, columns < cols; ld, cols % 8 == 0; the context must be in plane format 1): ADDS to
- * stats4_dev[0..3] (uint64, device) the elements looked at, the non-zero halves, the halves AT the encode's clamp (|h| >= 28 672) and
- * the subnormal halves (0 < |h| < 2^-14).  within (may be NULL): uint8 flags of the 32-row blocks to look at.  The P16 encode clamps
+ * stats5_dev[0..3] (uint64, device) the elements looked at, the non-zero halves, the halves AT the encode's clamp (|h| >= 28 672) and
+ * the subnormal halves (0 < |h| < 2^-14); stats5_dev[4] = max(stats5_dev[4], largest |half| seen as its 15 bits).  within (may be NULL): uint8 flags of the 32-row blocks to look at.  The P16 encode clamps
  * and a half underflows silently (csrc/p16.h); this is how a caller sees whether a step came near either end: Engine.p16_stats(),
  * asserted in tests/test_gpu_parity.py, printed by bench.py.  No reference counterpart (the reference computes in float32). */
 int pp_planes_stats(pp_ctx* ctx, const void* hi, const void* lo, long long rows, int ld, int cols, const unsigned char* within,
-                    unsigned long long* stats4_dev);
+                    unsigned long long* stats5_dev);
 /* [n_img,h,w,3] -> [n_img,h,w,4] zero-padded channel (feeds conv1 as cin == 4) */
 int pp_pack_rgb_to_4(pp_ctx* ctx, size_t n_pixels, const float* x3, float* x4);
 /* utils/image.py:35-62 preprocess_image(mode='caffe') + preprocessing/generator.py:319-336 compute_inputs in one pass:

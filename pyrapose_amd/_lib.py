@@ -94,6 +94,7 @@ _SIGS = {
     "pp_convert_planes": (_i, [_p, _sz, _p, _p, _i, _p, _p, _i, _p, _i, _p]),
     "pp_split_planes_scaled_bf16x3": (_i, [_p, _sz, _p, _p, _p, _p]),
     "pp_grad_scale_from_counts": (_i, [_p, _p, _i, _p]),
+    "pp_grad_scale_from_counts_adj": (_i, [_p, _p, _i, _p, _i]),
     "pp_ctx_set_grad_scale": (_i, [_p, _p]),
     "pp_planes_stats": (_i, [_p, _p, _p, _ll, _i, _i, _p, _p]),
     "pp_ctx_set_workspace": (_i, [_p, _p, C.c_size_t]),

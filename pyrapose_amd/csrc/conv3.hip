@@ -1131,13 +1131,17 @@ extern "C" int PP_API(pp_split_planes_scaled_bf16x3)(pp_ctx* ctx, size_t n, cons
 }
 namespace {
 }  // namespace
-extern "C" int PP_API(pp_grad_scale_from_counts)(pp_ctx* ctx, const int* counts_dev, int n_counts, float* scale2_dev) {
+extern "C" int PP_API(pp_grad_scale_from_counts_adj)(pp_ctx* ctx, const int* counts_dev, int n_counts, float* scale2_dev, int log2_adjust) {
   PP_REQUIRE_CTX(ctx);
-  PP_CHECK_ARG(ctx, counts_dev && scale2_dev && n_counts >= 1 && n_counts <= 16, PP_ERR_ARG, "pp_grad_scale_from_counts: bad arguments");
+  PP_CHECK_ARG(ctx, counts_dev && scale2_dev && n_counts >= 1 && n_counts <= 16 && log2_adjust >= -16 && log2_adjust <= 16, PP_ERR_ARG,
+               "pp_grad_scale_from_counts: bad arguments");
   static const int base_log2 = []() { const char* e = getenv("PP_GSCALE_LOG2"); const int v = e ? atoi(e) : 8; return v < -20 ? -20 : (v > 30 ? 30 : v); }();
-  hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(64), 0, ctx->stream, counts_dev, n_counts, scale2_dev, base_log2);
+  hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(64), 0, ctx->stream, counts_dev, n_counts, scale2_dev, base_log2 + log2_adjust);
   PP_CHECK_LAUNCH(ctx, "pp_grad_scale_from_counts");
   return PP_OK;
+}
+extern "C" int PP_API(pp_grad_scale_from_counts)(pp_ctx* ctx, const int* counts_dev, int n_counts, float* scale2_dev) {
+  return PP_API(pp_grad_scale_from_counts_adj)(ctx, counts_dev, n_counts, scale2_dev, 0);
 }
 namespace {
 static int split_planes_impl(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo, const float* scale) {

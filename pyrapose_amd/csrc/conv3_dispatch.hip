@@ -13,6 +13,8 @@ extern "C" int pp_split_planes_bf16x3_fmt1(pp_ctx* ctx, size_t n, const float* s
 extern "C" int pp_split_planes_scaled_bf16x3_fmt0(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo, const float* scale_dev);
 extern "C" int pp_split_planes_scaled_bf16x3_fmt1(pp_ctx* ctx, size_t n, const float* src, void* hi, void* lo, const float* scale_dev);
 extern "C" int pp_grad_scale_from_counts_fmt0(pp_ctx* ctx, const int* counts_dev, int n_counts, float* scale2_dev);
+extern "C" int pp_grad_scale_from_counts_adj_fmt0(pp_ctx* ctx, const int* counts_dev, int n_counts, float* scale2_dev, int log2_adjust);
+extern "C" int pp_grad_scale_from_counts_adj_fmt1(pp_ctx* ctx, const int* counts_dev, int n_counts, float* scale2_dev, int log2_adjust);
 extern "C" int pp_grad_scale_from_counts_fmt1(pp_ctx* ctx, const int* counts_dev, int n_counts, float* scale2_dev);
 extern "C" int pp_conv_split_weights_bf16x3_batch_fmt0(pp_ctx* ctx, int n_jobs, const pp_split_job* jobs_dev, int total_tiles);
 extern "C" int pp_conv_split_weights_bf16x3_batch_fmt1(pp_ctx* ctx, int n_jobs, const pp_split_job* jobs_dev, int total_tiles);
@@ -46,6 +48,9 @@ extern "C" int pp_split_planes_scaled_bf16x3(pp_ctx* ctx, size_t n, const float*
 }
 extern "C" int pp_grad_scale_from_counts(pp_ctx* ctx, const int* counts_dev, int n_counts, float* scale2_dev) {
   return (ctx && ctx->planes_fmt == 1) ? pp_grad_scale_from_counts_fmt1(ctx, counts_dev, n_counts, scale2_dev) : pp_grad_scale_from_counts_fmt0(ctx, counts_dev, n_counts, scale2_dev);
+}
+extern "C" int pp_grad_scale_from_counts_adj(pp_ctx* ctx, const int* counts_dev, int n_counts, float* scale2_dev, int log2_adjust) {
+  return (ctx && ctx->planes_fmt == 1) ? pp_grad_scale_from_counts_adj_fmt1(ctx, counts_dev, n_counts, scale2_dev, log2_adjust) : pp_grad_scale_from_counts_adj_fmt0(ctx, counts_dev, n_counts, scale2_dev, log2_adjust);
 }
 extern "C" int pp_conv_split_weights_bf16x3_batch(pp_ctx* ctx, int n_jobs, const pp_split_job* jobs_dev, int total_tiles) {
   return (ctx && ctx->planes_fmt == 1) ? pp_conv_split_weights_bf16x3_batch_fmt1(ctx, n_jobs, jobs_dev, total_tiles) : pp_conv_split_weights_bf16x3_batch_fmt0(ctx, n_jobs, jobs_dev, total_tiles);

@@ -422,12 +422,13 @@ extern "C" int pp_merge_planes_bf16x3(pp_ctx* ctx, size_t n, const void* hi, con
 // ---- audit of a P16 tensor: where do its halves sit in the format's range? ----
 // P16 clamps |x| to 28 672 when it encodes and a half stops at 6e-8 (planes_fmt.h): neither leaves a trace in the tensor's consumers.
 // This pass reads the hi plane of a tensor [rows][ld] (packed planes; columns < cols) and ADDS to stats[0..3]: elements looked at,
+// (stats[4] = the largest |half| seen, as its 15 bits, by atomic max: how much of the range the tensor uses)
 // non-zero halves, halves AT the clamp (|h| >= 28 672: a saturated encode), SUBNORMAL halves (0 < |h| < 2^-14: the element lost
 // significand bits -- with the gradient scale 2^G of pp_grad_scale_from_counts that is where a too-small G shows).  within (may be
 // NULL): uint8 flags of the 32-row blocks to look at (a lazily filled sparse gradient is undefined outside its flagged blocks).
 __global__ void planes_stats_kernel(const uint4* __restrict__ hi, long long rows, int ld8, int cols8, const unsigned char* __restrict__ within,
                                     unsigned long long* __restrict__ stats) {
-  unsigned long long n = 0, nz = 0, clamp = 0, sub = 0;
+  unsigned long long n = 0, nz = 0, clamp = 0, sub = 0, amax = 0;
   const long long total = rows * cols8;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long r = i / cols8;
@@ -444,26 +445,30 @@ __global__ void planes_stats_kernel(const uint4* __restrict__ hi, long long rows
         nz += a != 0u;
         clamp += a >= 0x7700u;           // 28 672 = 0x7700 as a half (NaN / infinity patterns land here too)
         sub += a != 0u && a < 0x0400u;   // below the smallest normal half 2^-14
+        amax = a > amax ? a : amax;
       }
   }
   // wave reduction, then one atomic per wave and counter
   for (int o = 32; o > 0; o >>= 1) {
     n += __shfl_down(n, o, 64); nz += __shfl_down(nz, o, 64); clamp += __shfl_down(clamp, o, 64); sub += __shfl_down(sub, o, 64);
+    const unsigned long long om = __shfl_down(amax, o, 64);
+    amax = om > amax ? om : amax;
   }
   if ((threadIdx.x & 63) == 0) {
     atomicAdd(stats + 0, n); atomicAdd(stats + 1, nz); atomicAdd(stats + 2, clamp); atomicAdd(stats + 3, sub);
+    atomicMax(stats + 4, amax);
   }
 }
 
 extern "C" int pp_planes_stats(pp_ctx* ctx, const void* hi, const void* lo, long long rows, int ld, int cols, const unsigned char* within,
-                               unsigned long long* stats4_dev) {
+                               unsigned long long* stats5_dev) {
   PP_REQUIRE_CTX(ctx);
-  PP_CHECK_ARG(ctx, hi && lo && stats4_dev && rows >= 0 && ld > 0 && ld % 8 == 0 && cols > 0 && cols % 8 == 0 && cols <= ld && pp_is_packed(hi, lo),
+  PP_CHECK_ARG(ctx, hi && lo && stats5_dev && rows >= 0 && ld > 0 && ld % 8 == 0 && cols > 0 && cols % 8 == 0 && cols <= ld && pp_is_packed(hi, lo),
                PP_ERR_ARG, "pp_planes_stats: packed planes, ld and cols multiples of 8");
   PP_CHECK_ARG(ctx, ctx->planes_fmt == 1, PP_ERR_ARG, "pp_planes_stats: a P16 context (pp_ctx_set_planes_format(ctx, 1)): bf16 pairs keep the f32 range");
   if (rows == 0) return PP_OK;
   hipLaunchKernelGGL(planes_stats_kernel, dim3(grid_for((size_t)rows * (cols / 8), 256, ctx)), dim3(256), 0, ctx->stream, (const uint4*)hi, rows,
-                     ld / 8, cols / 8, within, stats4_dev);
+                     ld / 8, cols / 8, within, stats5_dev);
   PP_CHECK_LAUNCH(ctx, "pp_planes_stats");
   return PP_OK;
 }

@@ -354,6 +354,11 @@ class Engine(object):
         # step (pp_grad_scale_from_counts), multiplies the three loss gradients when they are split into planes, rides through
         # every bwd-data / pointwise launch, and is divided out by the weight-gradient launches (pp_ctx_set_grad_scale).
         self.gscale = None
+        # loss weights above the reference's defaults (orthogonal_l1 weight 0.125, focal alpha 0.25) scale the loss gradients up: take
+        # that factor out of the power-of-two gradient scale, so that the headroom under the P16 clamp stays what it is at the defaults
+        import math as _math
+        ratio = max(self.loss_params["box"][0] / 0.125, self.loss_params["cls"][0] / 0.25, self.loss_params["mask"][0] / 0.25, 1.0)
+        self.gscale_adjust = -int(_math.ceil(_math.log2(ratio)))
         from ._lib import MISSING as _missing
         if self.train and self.po and self.arith in ("f16c8", "mixed") and "pp_grad_scale_from_counts" not in _missing:
             self.gscale = torch.ones((2,), dtype=torch.float32, device="cuda")
@@ -1205,7 +1210,7 @@ class Engine(object):
             if self.grad_sync is not None:
                 self.grad_sync.reduce_counts(self.counts)
             if self.gscale is not None:
-                ops.grad_scale_from_counts(ctx, self.counts[0:3], self.gscale)
+                ops.grad_scale_from_counts(ctx, self.counts[0:3], self.gscale, self.gscale_adjust)
         (bw, bs), (ca, cg), (ma, mg) = self.loss_params["box"], self.loss_params["cls"], self.loss_params["mask"]
         ops.orth_l1(ctx, self.pyr.rowspace(), self.A, self.reg_out.t, self.y_box, bw, bs, self.counts[0:1], 1.0,
                     self.loss_sums[0:1], self.g_reg)
@@ -1331,16 +1336,19 @@ class Engine(object):
 
     def p16_stats(self):
         """Where the halves of this plan's P16 tensors sit in the format's range, after the last forward / train step
-        (pp_planes_stats): {'activations' | 'gradients': {'elements', 'nonzero', 'clamped', 'subnormal'}} plus 'grad_scale_log2'.
+        (pp_planes_stats): {'activations' | 'gradients': {'elements', 'nonzero', 'clamped', 'subnormal', 'max_abs'}} plus
+        'grad_scale_log2'.
         `clamped` counts halves AT the encode's clamp (|x| >= 28 672: the P16 encode saturates silently), `subnormal` non-zero
-        halves below 2^-14 (the element has lost significand bits; for gradients: the power-of-two scale 2^G is too small).  Lazily
+        halves below 2^-14 (the element has lost significand bits: harmless for the many near-zero elements of a gradient -- their
+        absolute error stays 2^-25 -- and a warning only when `max_abs`, the largest |half| of the group, is small itself: then the
+        power-of-two gradient scale 2^G is too small).  Lazily
         filled sparse gradients are read inside their flagged blocks only.  An audit pass over HBM (~0.3 ms per GB): never timed."""
         torch.cuda.synchronize()
         ctx1 = self.ctx.twin(1)
         out = {}
         for kind, items in (("activations", [(a.pl, None) for a in self.acts.values() if a.pl is not None and a.fmt == 1]),
                             ("gradients", [(g.pl, (g.within if g.lazy else None)) for g in self._plane_grads if g.pl is not None and g.fmt == 1])):
-            st = torch.zeros((4,), dtype=torch.int64, device="cuda")
+            st = torch.zeros((5,), dtype=torch.int64, device="cuda")
             spans = []  # byte ranges already counted (the pyramid levels are slices of one buffer: largest tensors first)
             for pl, within in sorted(items, key=lambda it: -it[0][0].shape[0]):
                 ld = ops.planes_ld(pl)
@@ -1351,7 +1359,8 @@ class Engine(object):
                 spans.append((a, b))
                 ops.planes_stats(ctx1, pl, ld, st, within)
             v = st.cpu().numpy()
-            out[kind] = dict(elements=int(v[0]), nonzero=int(v[1]), clamped=int(v[2]), subnormal=int(v[3]))
+            out[kind] = dict(elements=int(v[0]), nonzero=int(v[1]), clamped=int(v[2]), subnormal=int(v[3]),
+                             max_abs=float(np.array([int(v[4])], np.uint16).view(np.float16)[0]))
         if self.gscale is not None:
             out["grad_scale_log2"] = float(torch.log2(self.gscale[0]).cpu())
         return out

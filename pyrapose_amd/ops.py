@@ -198,8 +198,9 @@ def split_planes3(ctx, src, hi, lo, scale=None):
               "pp_split_planes_scaled_bf16x3")
 
 
-def grad_scale_from_counts(ctx, counts, scale2):
-    check(lib.pp_grad_scale_from_counts(ctx.handle, _ptr(counts), int(counts.numel()), _ptr(scale2)), ctx.handle, "pp_grad_scale_from_counts")
+def grad_scale_from_counts(ctx, counts, scale2, log2_adjust=0):
+    check(lib.pp_grad_scale_from_counts_adj(ctx.handle, _ptr(counts), int(counts.numel()), _ptr(scale2), int(log2_adjust)), ctx.handle,
+          "pp_grad_scale_from_counts")
 
 
 def set_grad_scale(ctx, scale2):
@@ -289,7 +290,8 @@ def merge_planes3(ctx, planes, dst):
 
 
 def planes_stats(ctx, planes, cols, stats, within=None):
-    """pp_planes_stats: adds (elements, non-zero, at the clamp, subnormal) of a P16 tensor's halves to stats (int64 [4], device);
+    """pp_planes_stats: adds (elements, non-zero, at the clamp, subnormal) of a P16 tensor's halves to stats[0..3] and keeps the largest
+    |half| (15 bits) in stats[4] (int64 [5], device);
     ctx must be the P16 twin; within = uint8 flags of the 32-row blocks to look at"""
     hi, lo = planes
     check(lib.pp_planes_stats(ctx.handle, _ptr(hi), _ptr(lo), int(hi.shape[0]), planes_ld(planes), int(cols), _ptr(within), _ptr(stats)), ctx.handle,

@@ -107,6 +107,9 @@ def test_grad_scale_from_counts(ctx, counts, want, monkeypatch):
     ops.grad_scale_from_counts(ctx, c, s)
     a, b = s.cpu().tolist()
     assert a == 2.0 ** (8 + want) and b == 2.0 ** -(8 + want)
+    # loss weights above the reference's defaults take their factor out of the scale (Engine.gscale_adjust)
+    ops.grad_scale_from_counts(ctx, c, s, log2_adjust=-3)
+    assert s.cpu().tolist() == [2.0 ** (5 + want), 2.0 ** -(5 + want)]
 
 
 def _run(ctx, mode, Wt, x, tg, C, B, H, W):

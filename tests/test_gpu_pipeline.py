@@ -124,8 +124,12 @@ def test_u8_look_ahead_with_augmentation(ctx, monkeypatch):
     eng.close()
 
 
-def test_sparse_forward_of_box_head_is_exact_for_training(ctx, monkeypatch):
-    """PP_SPARSE_FWD=1: in a training step the 3D-box head computes only the 32-row blocks its loss reads (anchors with state 1,
+@pytest.mark.parametrize("mode", ["bf16x3", "mixed"])
+def test_sparse_forward_of_box_head_is_exact_for_training(ctx, monkeypatch, mode):
+    """(the bounds below were widened 40-100x for the f16c8 heads of the mixed mode, where a stale 32-row block in a
+    low-magnitude region would no longer fail; the all-bf16x3 arithmetic runs the same plan -- lazy sparse gradients included --
+    and keeps the tight bounds.)
+    PP_SPARSE_FWD=1: in a training step the 3D-box head computes only the 32-row blocks its loss reads (anchors with state 1,
     losses.py:332-333) and what those need, layer by layer.  Losses, gradients and updated weights equal the dense forward's
     (different kernel for the listed blocks: f32 summation order), step after step with new targets; forward() outside a
     training step still computes every row."""
@@ -141,10 +145,11 @@ def test_sparse_forward_of_box_head_is_exact_for_training(ctx, monkeypatch):
     # precision step after step -- with new inputs and targets each time, i.e. with stale rows of the step before lying around;
     # a fourth step with lr > 0 compares the updated weights)
     monkeypatch.delenv("PP_SPARSE_FWD", raising=False)
-    a = Engine(ctx, Cq, Bq, Hq, Wq, weights=Wt, train=True, lr=0.0)
+    a = Engine(ctx, Cq, Bq, Hq, Wq, weights=Wt, train=True, lr=0.0, conv_mode=mode)
     monkeypatch.setenv("PP_SPARSE_FWD", "1")
-    b = Engine(ctx, Cq, Bq, Hq, Wq, weights=Wt, train=True, lr=0.0)
+    b = Engine(ctx, Cq, Bq, Hq, Wq, weights=Wt, train=True, lr=0.0, conv_mode=mode)
     assert b.sparse_fwd and not a.sparse_fwd
+    tight = mode == "bf16x3"  # (2^-17 per stored value: the round-2 bounds)
     for i in range(4):
         if i == 3:
             a.lr = b.lr = 1e-4
@@ -161,7 +166,7 @@ def test_sparse_forward_of_box_head_is_exact_for_training(ctx, monkeypatch):
         # (the listed-block launch sums in another order than the dense kernel: ~2e-5 per activation in the f16c8 arithmetic, and a
         # ReLU input of the head that is zero to rounding may flip -- 8e-3 of the gradient's scale has been seen; a stale row
         # would show as O(1))
-        assert float((ga - gb).abs().max()) <= 2e-2 * float(ga.abs().max()), i
+        assert float((ga - gb).abs().max()) <= (5e-4 if tight else 2e-2) * float(ga.abs().max()), i
     # a batch without a single positive anchor: nothing of the head is computed, its loss and gradient are zero in both engines
     a.lr = b.lr = 0.0
     tg = [torch.from_numpy(t).cuda() for t in random_targets(rng, Bq, a.N, a.M3, Cq, pos_frac=0.0)]
@@ -175,7 +180,7 @@ def test_sparse_forward_of_box_head_is_exact_for_training(ctx, monkeypatch):
         assert abs(la[k] - lb[k]) <= 2e-5 * max(abs(la[k]), 1e-3), (k, la[k], lb[k])
     # (without the box loss the largest gradient is ~7e-3 while the float32 atomics of the weight gradients still scatter ~4e-6:
     # an absolute floor beside the relative bound)
-    assert float((a.params.grad - b.params.grad).abs().max()) <= 2e-3 * float(a.params.grad.abs().max()) + 2e-5
+    assert float((a.params.grad - b.params.grad).abs().max()) <= (5e-4 if tight else 2e-3) * float(a.params.grad.abs().max()) + 2e-5
     wa, wb = a.params.w_master, b.params.w_master
     # (one Adam step moves every weight by ~lr whatever the size of its gradient: where the two gradients are noise of opposite
     # sign the weights part by 2 lr -- that, not a relative bound, is the scale of an honest difference)
@@ -187,6 +192,13 @@ def test_sparse_forward_of_box_head_is_exact_for_training(ctx, monkeypatch):
     torch.cuda.synchronize()
     ra, rb = a.reg_out.t[:, : a.reg_out.C], b.reg_out.t[:, : b.reg_out.C]
     assert float((ra - rb).abs().max()) <= 2e-3 * float(ra.abs().max())
+    if tight:  # the same weights in both engines: the final forwards agree at kernel precision
+        b.params.w_master.copy_(a.params.w_master)
+        b.params.w_eff.copy_(a.params.w_eff)
+        b.refresh_planes()
+        b.forward(xs[0])
+        torch.cuda.synchronize()
+        assert float((ra - b.reg_out.t[:, : b.reg_out.C]).abs().max()) <= 2e-5 * float(ra.abs().max())
     a.close()
     b.close()
 
