@@ -31,6 +31,8 @@ extern "C" {
 #define PP_ERR_SHAPE (-2)
 #define PP_ERR_ALIGN (-3)
 #define PP_ERR_NOCTX (-4)
+#define PP_ERR_UNSUPPORTED (-5) /* an optional dependency is missing (librccl.so for the pp_comm_* / pp_allreduce_* entry points) */
+#define PP_ERR_COMM (-6)        /* RCCL returned an error (text in pp_last_error) */
 
 #define PP_MAX_SEG 5
 
@@ -216,6 +218,25 @@ int pp_conv2d_nhwc_bwd_data_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const flo
 int pp_conv2d_nhwc_bwd_weight_bf16x3(pp_ctx* ctx, const pp_conv_desc* d, const float* x, const float* dy,
                                      const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo,
                                      float* dw, float* dbias);
+
+/* ---- data-parallel gradient exchange on RCCL -----------------------------------------------------------
+ * The reference trains on one device (bin/train.py:82-89: the multi_gpu_model branch is disabled); what its single-device
+ * semantics fix is that the loss normalisers count positives over the WHOLE batch (losses.py:62-66, :402-405) and that Adam clips
+ * by the GLOBAL gradient norm (bin/train.py:101).  With the batch sharded per image over one process per GPU that takes a SUM
+ * all-reduce of the three positive counts and a SUM all-reduce of the flat gradient buffer -- here as plain entry points on a
+ * communicator the library owns, so that the engine decides the stream (its own), the bucket and the moment (pyrapose_amd/
+ * parallel.py launches a bucket as soon as the last weight-gradient kernel that writes into it is enqueued).
+ * librccl.so is loaded with dlopen on first use (PP_RCCL_LIB overrides the name); without it these calls return
+ * PP_ERR_UNSUPPORTED and pp_comm_available() is 0.  id128: the 128 bytes of an ncclUniqueId -- rank 0 calls pp_comm_unique_id and
+ * hands the bytes to every rank by any channel; pp_comm_init is collective over the `world` ranks (one communicator per process,
+ * bound to the context's device).  All-reduces run in place, asynchronously, on the context's stream. */
+typedef struct pp_comm pp_comm;
+int pp_comm_available(void);
+int pp_comm_unique_id(pp_ctx* ctx, void* id128);
+int pp_comm_init(pp_ctx* ctx, int world, int rank, const void* id128, pp_comm** out);
+int pp_comm_destroy(pp_comm* comm);
+int pp_allreduce_bucket(pp_ctx* ctx, pp_comm* comm, float* buf, size_t count);
+int pp_allreduce_counts(pp_ctx* ctx, pp_comm* comm, int* counts, int n);
 
 /* ---- pooling / resampling / pointwise --------------------------------------------------
  * keras_resnet pool1 = MaxPooling2D(3, strides 2, 'same') (called via models/resnet.py:87). */

@@ -97,6 +97,12 @@ _SIGS = {
     "pp_grad_scale_from_counts_adj": (_i, [_p, _p, _i, _p, _i]),
     "pp_ctx_set_grad_scale": (_i, [_p, _p]),
     "pp_planes_stats": (_i, [_p, _p, _p, _ll, _i, _i, _p, _p]),
+    "pp_comm_available": (_i, []),
+    "pp_comm_unique_id": (_i, [_p, _p]),
+    "pp_comm_init": (_i, [_p, _i, _i, _p, C.POINTER(_p)]),
+    "pp_comm_destroy": (_i, [_p]),
+    "pp_allreduce_bucket": (_i, [_p, _p, _p, C.c_size_t]),
+    "pp_allreduce_counts": (_i, [_p, _p, _p, _i]),
     "pp_ctx_set_workspace": (_i, [_p, _p, C.c_size_t]),
     "pp_ctx_set_split_capture": (_i, [_p, _p, _p]),
     "pp_row_block_list": (_i, [_p, _p, _i, _i, _i, _p, _p]),

@@ -144,8 +144,72 @@ def plan_buckets(entries, bwd_ops, bucket_bytes):
     return out
 
 
+class NativeComm(object):
+    """An RCCL communicator owned by the HIP library (include/pyrapose_hip.h: pp_comm_*, pp_allreduce_bucket; librccl.so through
+    dlopen) on a stream of the engine's own: the all-reduces are plain launches on that stream, ordered against the lanes with
+    stream waits -- no torch.distributed in the data path.  The 128-byte unique id is the only thing that needs a side channel."""
+
+    def __init__(self, device, world, rank, unique_id):
+        import ctypes as C
+        from . import ops
+        from ._lib import check, lib
+        self.world, self.rank = int(world), int(rank)
+        self.stream = torch.cuda.Stream(device)
+        self.ctx = ops.Context(device, self.stream)
+        self.handle = C.c_void_p()
+        self._id = C.create_string_buffer(bytes(unique_id), 128)
+        check(lib.pp_comm_init(self.ctx.handle, self.world, self.rank, self._id, C.byref(self.handle)), self.ctx.handle, "pp_comm_init")
+
+    @staticmethod
+    def available():
+        from ._lib import MISSING, lib
+        return "pp_comm_available" not in MISSING and bool(lib.pp_comm_available())
+
+    @staticmethod
+    def unique_id(device=0):
+        import ctypes as C
+        from . import ops
+        from ._lib import check, lib
+        ctx = ops.Context(device)
+        buf = C.create_string_buffer(128)
+        check(lib.pp_comm_unique_id(ctx.handle, buf), ctx.handle, "pp_comm_unique_id")
+        ctx.close()
+        return bytes(buf.raw)
+
+    def allreduce(self, t, after=None):
+        """in-place SUM all-reduce of a float32 device tensor on the communicator's stream, ordered after stream `after`"""
+        import ctypes as C
+        from ._lib import check, lib
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        self.stream.wait_stream(after if after is not None else torch.cuda.current_stream())
+        check(lib.pp_allreduce_bucket(self.ctx.handle, self.handle, C.c_void_p(t.data_ptr()), t.numel()), self.ctx.handle, "pp_allreduce_bucket")
+
+    def allreduce_counts(self, counts):
+        """in-place SUM all-reduce of an int32 device tensor, ordered on both sides with the CURRENT stream (the losses read it next)"""
+        import ctypes as C
+        from ._lib import check, lib
+        assert counts.is_cuda and counts.dtype == torch.int32 and counts.is_contiguous()
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        check(lib.pp_allreduce_counts(self.ctx.handle, self.handle, C.c_void_p(counts.data_ptr()), counts.numel()), self.ctx.handle,
+              "pp_allreduce_counts")
+        cur.wait_stream(self.stream)
+
+    def close(self):
+        from ._lib import lib
+        if self.handle:
+            torch.cuda.synchronize()
+            lib.pp_comm_destroy(self.handle)
+            self.handle = None
+        self.ctx.close()
+
+
 class DataParallel(object):
-    def __init__(self, engine, group=None, bucket_bytes=None):
+    def __init__(self, engine, group=None, bucket_bytes=None, native=None):
+        """native: True = the gradient / count all-reduces run on the library's own RCCL communicator (NativeComm: pp_allreduce_bucket
+        on a stream the engine owns); False = through torch.distributed (the host-layer fallback: gloo rehearsals, CPU tests);
+        None = native when the library can load RCCL, the tensors live on a GPU and the process group (if any) is an RCCL one
+        (PP_DP_NATIVE=0 / 1 overrides).  Without a process group, native=True builds a one-rank communicator."""
         self.eng, self.group = engine, group
         bucket_bytes = bucket_bytes_from_env() if bucket_bytes is None else bucket_bytes
         self.active = dist.is_initialized()
@@ -153,10 +217,25 @@ class DataParallel(object):
             raise RuntimeError("DataParallel: WORLD_SIZE=%s but torch.distributed is not initialised -- every rank would silently train "
                                "its own copy; call parallel.ensure_process_group() first" % os.environ["WORLD_SIZE"])
         self.world = dist.get_world_size(group) if self.active else 1
+        self.native = None
+        on_gpu = engine.params.grad.is_cuda
+        env = os.environ.get("PP_DP_NATIVE")
+        if native is None:
+            native = (env != "0") and on_gpu and NativeComm.available() and ((self.active and dist.get_backend(group) == "nccl") or env == "1")
+        if native:
+            if not (on_gpu and NativeComm.available()):
+                raise RuntimeError("DataParallel(native=True): needs device tensors and a loadable librccl.so (PP_RCCL_LIB)")
+            dev = engine.params.grad.device.index or 0
+            rank = dist.get_rank(group) if self.active else 0
+            box = [NativeComm.unique_id(dev) if rank == 0 else None]
+            if self.active and self.world > 1:
+                dist.broadcast_object_list(box, src=0, group=group)  # (the id's only journey; the data path never sees torch.distributed)
+            self.native = NativeComm(dev, self.world, rank, box[0])
         self.buckets = plan_buckets(engine.params.entries, engine.bwd_ops, bucket_bytes)
         if os.environ.get("PP_DP_DEBUG") == "1":
             rank = dist.get_rank(group) if self.active else 0
-            print("[pyrapose_amd.parallel rank %d/%d] %s" % (rank, self.world, describe_buckets(self.buckets, engine.bwd_ops)), flush=True)
+            print("[pyrapose_amd.parallel rank %d/%d] %s\n  all-reduce path: %s" % (rank, self.world, describe_buckets(self.buckets, engine.bwd_ops),
+                  "pp_allreduce_bucket (library-owned RCCL communicator)" if self.native is not None else "torch.distributed"), flush=True)
         self.by_op = {}
         for (a, b, r) in self.buckets:
             self.by_op.setdefault(r, []).append((a, b))
@@ -166,11 +245,16 @@ class DataParallel(object):
         engine.grad_sync = self
 
     def reduce_counts(self, counts):
-        if self.active:
+        if self.native is not None:
+            self.native.allreduce_counts(counts)
+        elif self.active:
             dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
 
     def _launch(self, a, b, stream=None):
         t = self.flat[a:b]
+        if self.native is not None:
+            self.native.allreduce(t, after=stream)
+            return
         if not self.active:
             return
         if self.on_gpu:
@@ -191,6 +275,9 @@ class DataParallel(object):
         for (a, b) in self.by_op.get(-1, ()):  # buckets no weight-gradient op maps to (defensive)
             self._launch(a, b)
         st = getattr(self.eng, "streams", None)
+        if self.native is not None:
+            (st[0] if st else torch.cuda.current_stream()).wait_stream(self.native.stream)  # the optimizer runs on the engine's lane 0
+            return
         if self.on_gpu and st:
             with torch.cuda.stream(st[0]):  # the optimizer runs on the engine's lane 0
                 for w in self.works:

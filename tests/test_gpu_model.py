@@ -282,6 +282,46 @@ def test_data_parallel_path_single_rank_nccl(ctx):
         dist.destroy_process_group()
 
 
+def test_data_parallel_on_the_librarys_own_rccl_communicator_single_rank(ctx):
+    """VERDICT r03 item 6a / SURVEY 8b: pp_allreduce_bucket -- the gradient buckets and the positive counts all-reduced on an RCCL
+    communicator the LIBRARY owns (librccl.so through dlopen, pp_comm_init), on a stream of the engine's own, no torch.distributed
+    anywhere.  A one-rank communicator must reproduce the plain step: same counts, same gradient, same weights after the update."""
+    from pyrapose_amd import arch
+    from pyrapose_amd.engine import Engine
+    from pyrapose_amd.parallel import DataParallel, NativeComm
+    assert NativeComm.available()
+    B, H, W, C = 2, 64, 96, 5
+    rng = np.random.default_rng(6)
+    Wt = arch.init_weights(C, seed=7)
+    x = torch.from_numpy(synth_input(rng, B, H, W)).cuda()
+    ref = Engine(ctx, C, B, H, W, weights=Wt, train=True)
+    tg = [torch.from_numpy(a).cuda() for a in random_targets(rng, B, ref.N, ref.M3, C)]
+    ref.train_step(x, tg)
+    torch.cuda.synchronize()
+    eng = Engine(ctx, C, B, H, W, weights=Wt, train=True)
+    dp = DataParallel(eng, bucket_bytes=8 << 20, native=True)
+    try:
+        assert dp.native is not None and dp.native.world == 1 and len(dp.buckets) >= 3
+        eng.train_step(x, tg)
+        torch.cuda.synchronize()
+        assert torch.equal(eng.counts, ref.counts)
+        # (atomics make the weight-gradient sums order-dependent in the last bits)
+        assert float((eng.params.grad - ref.params.grad).abs().max()) <= 1e-5 * float(ref.params.grad.abs().max())
+        assert float((eng.params.w_master - ref.params.w_master).abs().max()) <= 2.5e-5  # (one Adam step: lr 1e-5 per weight at most twice)
+        got, want = eng.losses(), ref.losses()
+        assert all(abs(got[k] - want[k]) <= 1e-6 * max(abs(want[k]), 1e-3) for k in want)
+        # the raw entry point: a SUM over one rank leaves the buffer as it is
+        t = torch.arange(1000, dtype=torch.float32, device="cuda")
+        dp.native.allreduce(t)
+        torch.cuda.synchronize()
+        assert torch.equal(t, torch.arange(1000, dtype=torch.float32, device="cuda"))
+    finally:
+        eng.grad_sync = None
+        dp.native.close()
+        eng.close()
+        ref.close()
+
+
 def test_two_rank_data_parallel_equals_global_batch(ctx, tmp_path, monkeypatch):
     """two ranks with two images each (count exchange + bucketed gradient all-reduce, gloo here because the
     ranks share the box's one GPU) must take the step a single process takes on the global batch of four: same positive
