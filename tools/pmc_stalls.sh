@@ -15,7 +15,7 @@ for C in "SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_
          "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INST_CYCLES_VMEM_RD SQ_INSTS_VMEM_RD" \
          "SQ_VALU_MFMA_COEXEC_CYCLES SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_LDS_ADDR_CONFLICT" \
          "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVES" \
-         "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES"; do
+         "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$i -- python3 $ROOT/tools/conv_bench.py --shape ${SHAPE:-reg} --iters 3 --fmt ${FMT:-1} --mode ${MODES:-fwd3pp,wgrad3p} > $OUT/pmc_$i.log 2>&1
 done
