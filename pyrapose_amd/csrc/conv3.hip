@@ -887,6 +887,9 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void igemm4x_kernel(
     sA1[8 * BM] = make_uint4(0u, 0u, 0u, 0u);
     sA1[8 * BM + 1] = make_uint4(0u, 0u, 0u, 0u);
   }
+  // VAR & 8 (round 4, measured A/B): static priority for the second-dispatched half of an 8-wave workgroup (cdna_hip_programming.md T5,
+  // static form: the younger waves lose the issue arbitration on every segment)
+  if ((VAR & 8) && NWM == 4 && wave >= 4) __builtin_amdgcn_s_setprio(1);
   // prologue: group 0 and the weight tiles of taps 0, 1 (BST == 2: of tap 0)
   dma_a(0, sA0);
   dma_b(0, 0, sB0);
@@ -1496,7 +1499,8 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
             p.n_tiles_n = ntn;
             // scheduling variants (measured on the regression-head launch, P16): 1 = no iglp_opt hint in the k-step (default: 442 us
             // against 465 with igemm3x's hint, 0), 2 / 3 = s_setprio around the MFMAs of 0 / 1 (466 / 461), 4 = igemm3f's sched_barrier
-            static const int var = []() { const char* e = getenv("PP_CONV3_DMA_VAR"); return e ? atoi(e) : 1; }();
+            const char* const e_var = getenv("PP_CONV3_DMA_VAR");  // (per launch: A/B in one process)
+            const int var = e_var ? atoi(e_var) : 1;
             auto go4 = [&](auto v) {
               hipLaunchKernelGGL((igemm4x_kernel<true, decltype(v)::value>), dim3((unsigned)(full_rt * ntn)), dim3(512), 0, st, p, ahi, alo,
                                  (unsigned)a_bytes, whi, wlo, (unsigned)w_bytes, p.bias, p.addend, p.mask_src, p.out, (uint2*)ohi, (uint2*)olo, w_rows,
@@ -1506,6 +1510,7 @@ static void launch_igemm3(hipStream_t st, IgemmParams& p, const void* ahi, const
             else if (var == 2) go4(std::integral_constant<int, 2>{});
             else if (var == 3) go4(std::integral_constant<int, 3>{});
             else if (var == 4) go4(std::integral_constant<int, 4>{});
+            else if (var == 9) go4(std::integral_constant<int, 9>{});
             else go4(std::integral_constant<int, 1>{});
             if (tail_splits > 1) {
               IgemmParams q = p;
