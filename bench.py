@@ -48,6 +48,8 @@ DTYPE_NOTES = {
 }
 
 EVENT_EVERY = 4  # per-launch HIP events on steps 0, 4, 8, ... of the timed region
+P16_AUDIT = {}           # Engine.p16_stats() of the most recent run() (rank 0)
+P16_AUDIT_HEADLINE = {}  # ... of the headline run
 
 
 def measured_peak(mode, achieved):  # achieved: MFMA-unit TFLOP/s (executed flops x units per product)
@@ -555,11 +557,20 @@ def main_worker(args):
         mode_used = "f32" if eng.conv_mode == "f32" else eng.arith  # the arithmetic that ran: f32 | bf16x3 | f16c8 | mixed
         if roof is None and sp_frac:
             roof = {"sparse": sp_frac}
+        # the P16 tensors of the last step (outside the timed region): nothing at the encode's clamp, largest |half| per group
+        # (Engine.p16_stats / pp_planes_stats: the format saturates and underflows silently, this is where it would show)
+        if rank == 0 and mode_used in ("mixed", "f16c8"):
+            try:
+                P16_AUDIT.clear()
+                P16_AUDIT.update(eng.p16_stats())
+            except Exception as e:  # noqa: BLE001 -- an audit, never a reason to lose the measurement
+                P16_AUDIT["error"] = repr(e)
         del eng
         torch.cuda.empty_cache()
         return dt, steps * B * world, losses, roof, mode_used
 
     dt, images_total, losses, roof, mode = run(args.conv_mode, args.steps, args.warmup, not args.no_kernel_events, args.dump_ops)
+    P16_AUDIT_HEADLINE.update(P16_AUDIT)
     prefetch_used = pf_flags[0]
 
     if rank != 0:
@@ -690,6 +701,7 @@ def main_worker(args):
         "step_tflops": images_total * algo_gflop / dt / 1e3,
         "losses": losses,
         "roofline": roofline, "cpu_baseline": cpu, "other_mode": other, "inference": inference,
+        "p16_audit": (dict(P16_AUDIT_HEADLINE) or None),
     }
     print(json.dumps(out))
     if world > 1:
