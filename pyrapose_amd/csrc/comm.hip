@@ -34,7 +34,8 @@ Rccl* rccl() {
   static bool tried = false;
   if (tried) return r.handle ? &r : nullptr;
   tried = true;
-  const char* names[] = {getenv("PP_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+  // (the soname first: in a process that has torch's bundled RCCL mapped, dlopen by soname returns THAT copy, not a second library)
+  const char* names[] = {getenv("PP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (const char* n : names) {
     if (!n || !n[0]) continue;
     r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);

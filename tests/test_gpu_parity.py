@@ -309,21 +309,22 @@ def _trained_weights(ctx, C, steps, lr, seed):
 
 def test_config1_train_step_on_trained_weights_vs_oracle_f64(ctx):
     """the 3.3x margin under the 1e-3 bar was measured on initialisation-scale weights only (heads N(0, 0.01)).
-    Here the config-1 step is compared with the float64 oracle on weights taken AFTER 2 000 optimisation steps of the default
+    Here the config-1 step is compared with the float64 oracle on weights taken AFTER 1 500 optimisation steps of the default
     (mixed-arithmetic) engine -- clipnorm-Adam at lr 2e-4: the total loss falls from 8.1 to below 2 and the head weights move by
     more than a sigma of their initialisation -- on a batch the training never saw."""
     import bench
     from pyrapose_amd.utils import anchors as UA
     B, H, W, C = 8, 480, 640, 13
-    Wt, first, last = _trained_weights(ctx, C, steps=2000, lr=2e-4, seed=0)
+    Wt, first, last = _trained_weights(ctx, C, steps=1500, lr=2e-4, seed=0)
     init = __import__("pyrapose_amd").arch.init_weights(C, seed=0)
     moved = {k: float(np.abs(np.asarray(Wt[k]) - np.asarray(init[k])).max()) for k in ("reg_conv3/kernel", "cls_out/kernel", "res4a_branch2a/kernel")}
     print("training: total loss %.4f -> %.4f; max |dw|: %s" % (first["total"], last["total"], moved))
     assert np.isfinite(last["total"]) and last["total"] < first["total"]
     assert moved["reg_conv3/kernel"] > 0.01  # (more than a sigma of the heads' N(0, 0.01): the weight distribution HAS changed)
-    x, images, anns = bench.synth_batch(B, H, W, C, seed=4242)
+    Bq = 4  # (four unseen images: the comparison costs a float64 forward + backward of the oracle on the host)
+    x, images, anns = bench.synth_batch(Bq, H, W, C, seed=4242)
     tg = UA.anchor_targets_bbox_device(UA.anchors_for_shape_device((H, W)), images, anns, C)
-    _train_step_vs_oracle(ctx, B, H, W, C, x, tg, Wt)
+    _train_step_vs_oracle(ctx, Bq, H, W, C, x, tg, Wt)
 
 
 @pytest.mark.parametrize("case", ["one_positive", "every_anchor_positive"])
