@@ -309,19 +309,19 @@ def _trained_weights(ctx, C, steps, lr, seed):
 
 def test_config1_train_step_on_trained_weights_vs_oracle_f64(ctx):
     """the 3.3x margin under the 1e-3 bar was measured on initialisation-scale weights only (heads N(0, 0.01)).
-    Here the config-1 step is compared with the float64 oracle on weights taken AFTER 1 500 optimisation steps of the default
+    Here the config-1 step is compared with the float64 oracle on weights taken AFTER 1 200 optimisation steps of the default
     (mixed-arithmetic) engine -- clipnorm-Adam at lr 2e-4: the total loss falls from 8.1 to below 2 and the head weights move by
     more than a sigma of their initialisation -- on a batch the training never saw."""
     import bench
     from pyrapose_amd.utils import anchors as UA
     B, H, W, C = 8, 480, 640, 13
-    Wt, first, last = _trained_weights(ctx, C, steps=1500, lr=2e-4, seed=0)
+    Wt, first, last = _trained_weights(ctx, C, steps=1200, lr=2e-4, seed=0)
     init = __import__("pyrapose_amd").arch.init_weights(C, seed=0)
     moved = {k: float(np.abs(np.asarray(Wt[k]) - np.asarray(init[k])).max()) for k in ("reg_conv3/kernel", "cls_out/kernel", "res4a_branch2a/kernel")}
     print("training: total loss %.4f -> %.4f; max |dw|: %s" % (first["total"], last["total"], moved))
     assert np.isfinite(last["total"]) and last["total"] < first["total"]
     assert moved["reg_conv3/kernel"] > 0.01  # (more than a sigma of the heads' N(0, 0.01): the weight distribution HAS changed)
-    Bq = 4  # (four unseen images: the comparison costs a float64 forward + backward of the oracle on the host)
+    Bq = 2  # (two unseen images: the comparison costs a float64 forward + backward of the oracle on the host)
     x, images, anns = bench.synth_batch(Bq, H, W, C, seed=4242)
     tg = UA.anchor_targets_bbox_device(UA.anchors_for_shape_device((H, W)), images, anns, C)
     _train_step_vs_oracle(ctx, Bq, H, W, C, x, tg, Wt)
@@ -331,10 +331,10 @@ def test_config1_train_step_on_trained_weights_vs_oracle_f64(ctx):
 def test_gradient_scale_extremes_vs_oracle_f64(ctx, case):
     """the P16 gradients travel multiplied by 2^G, G = 8 + floor(log2(min positive count)) (device,
     pp_grad_scale_from_counts).  The two ends at the real image size: ONE positive anchor and one positive mask cell in the batch
-    (G = 8, gradients as large as they get) and every anchor / cell positive (113 400 box and class positives, 9 600 mask positives
-    on two images: G = 21, gradients as small as they get) -- losses, every gradient tensor and the P16 audit against float64."""
+    (G = 8, gradients as large as they get) and every anchor / cell positive (56 700 box and class positives, 4 800 mask positives:
+    G = 20, gradients as small as they get) -- losses, every gradient tensor and the P16 audit against float64."""
     from pyrapose_amd import arch
-    B, H, W, C = (1, 480, 640, 13) if case == "one_positive" else (2, 480, 640, 13)
+    B, H, W, C = 1, 480, 640, 13
     rng = np.random.default_rng(91)
     x = synth_input(rng, B, H, W)
     N = sum(-(-H // 2 ** l) * -(-W // 2 ** l) for l in (3, 4, 5)) * 9

@@ -24,9 +24,9 @@ def test_config1_train_step_other_seeds(ctx, k):
     import bench
     from pyrapose_amd import arch
     from pyrapose_amd.utils import anchors as UA
-    # (seed 0 at the bench's batch of 8; the others on four images -- the float64 oracle on the host is what these tests cost,
-    # and the annotation density, not the batch, is what varies the gradient's support)
-    B, H, W, C = (8 if k == 0 else 4), 480, 640, 13
+    # (four images each -- tests/test_gpu_parity.py has the bench's batch of 8; the float64 oracle on the host is what these tests
+    # cost, and the annotation density, not the batch, is what varies the gradient's support)
+    B, H, W, C = 4, 480, 640, 13
     x, images, anns = bench.synth_batch(B, H, W, C, seed=2000 + 17 * k, boxes=(None, 1, 8, 15)[k % 4])
     tg = UA.anchor_targets_bbox_device(UA.anchors_for_shape_device((H, W)), images, anns, C)
     w, worst, total, _ = _train_step_vs_oracle(ctx, B, H, W, C, x, tg, arch.init_weights(C, seed=100 + k))
