@@ -595,7 +595,7 @@ def main_worker(args):
             if traffic is not None:
                 try:  # (the plane-format kernels = conv3.hip + the arithmetic header it is compiled against)
                     hsh = hashlib.sha256()
-                    for src in (["conv.hip"] if mode == "f32" else ["conv3.hip", "planes_fmt.h", "p16.h"]):
+                    for src in (["conv.hip"] if mode == "f32" else ["conv3.hip", "conv3_shared.h", "planes_fmt.h", "p16.h"]):
                         with open(os.path.join(ROOT, "pyrapose_amd", "csrc", src), "rb") as f:
                             hsh.update(f.read())
                     now = hsh.hexdigest()[:16]

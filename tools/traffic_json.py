@@ -66,7 +66,7 @@ def main():
                     "output channels and the workgroups of an XCD drift apart in phase, so the 9.4 MB of weights are re-fetched by every "
                     "round of workgroups on every XCD; at ~0.45-0.55 ms per launch this stays under a quarter of the HBM peak -- the launch "
                     "is bound by the matrix pipe and its feed, not by HBM.",
-            "kernel_source_sha16": sha(["conv3.hip", "planes_fmt.h", "p16.h"]),
+            "kernel_source_sha16": sha(["conv3.hip", "conv3_shared.h", "planes_fmt.h", "p16.h"]),
         }
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
