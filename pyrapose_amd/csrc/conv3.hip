@@ -2619,18 +2619,28 @@ extern "C" int PP_API(pp_conv2d_nhwc_bwd_weight_bf16x3)(pp_ctx* ctx, const pp_co
   // steps of a lone workgroup per CU plus the f32 atomics of splits x |dW|.  Register double-buffering of the staged tiles
   // (loads two steps ahead) shortens such lone-workgroup launches by 10-20 % in isolation, but no measurable step time.)
   {
-    // Round 4: 3x3 stride-1 "same" layers on plane-stored operands (heads, FPN, bottleneck 3x3) -> the tap-row-reuse kernel of
-    // conv4.hip (one staged tile pair per kernel ROW, 192 accumulators, double-buffered LDS); PP_WGRAD3R=0 (read per launch: tests
-    // compare the two kernels in one process) or the deterministic slices mode keep wgrad3f
+    // Round 4: 3x3 stride-1 "same" layers on plane-stored operands -> the tap-row-reuse kernels of conv4.hip (one staged tile pair per
+    // kernel ROW, 192 accumulators).  PP_WGRAD3R (read per launch: tests compare the kernels in one process):
+    //   unset  wgrad3w (producer + consumer waves) for the DENSE reductions of the P16 launches with 512 input or output channels --
+    //          the 3D-box head: 5-19 % faster per launch, +2.8 % on the dense-backward step; the 256-wide launches gain 5-13 % in
+    //          isolation and LOSE 1 % in the step (a workgroup of 8 waves x 256 registers owns its CU: nothing of the data-gradient
+    //          lane runs beside it), the bf16-pair launches of the backbone lose outright (profiles/r04_wgrad_producer_consumer_waves.txt);
+    //          PP_WGRAD3W_MIN moves the channel threshold
+    //   0      wgrad3f everywhere
+    //   1      wgrad3r (one wave per SIMD; dense launches 1.15-1.45x SLOWER than wgrad3f: profiles/r04_wgrad_tap_row_reuse.txt)
+    //   2      wgrad3w wherever its conditions hold
+    // The deterministic slices mode keeps wgrad3f.
     const char* const e_r = getenv("PP_WGRAD3R");
-    static const bool det = []() { const char* e = getenv("PP_WGRAD3_DETERMINISTIC"); return e && e[0] == '1'; }();
-    // OPT-IN (PP_WGRAD3R=1): results agree with wgrad3f to f32 summation order, but the dense launches are 1.15-1.45x SLOWER and
-    // the listed-block ones equal (profiles/r04_wgrad_tap_row_reuse.txt: one wave per SIMD leaves the step's ~400 instructions and
-    // the load latency uncovered)
-    if (e_r && e_r[0] == '1' && planes && !(det && ctx->ws != nullptr) && (!lazy_in || skip_list)) {
+    const char* const e_det = getenv("PP_WGRAD3_DETERMINISTIC");  // (read per launch, like the slices path itself)
+    const bool det = e_det && e_det[0] == '1';
+    static const int w_min = []() { const char* e = getenv("PP_WGRAD3W_MIN"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+    int variant = 0;
+    if (e_r && (e_r[0] == '1' || e_r[0] == '2')) variant = e_r[0] - '0';
+    else if (!e_r && PP_FMT == 1 && !skip_list && (d->cin >= w_min || d->cout >= w_min)) variant = 2;
+    if (variant && planes && !(det && ctx->ws != nullptr) && (!lazy_in || skip_list)) {
       static const int sp_steps = []() { const char* e = getenv("PP_WGRAD3_SP_STEPS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1; }();
       p.sp_min_steps = sp_steps;
-      if (PP_API(pp4_launch_wgrad3r)(ctx->stream, p, x_hi, x_lo, dy_hi, dy_lo, dw, dbias, skip_list, ctx->n_cu > 0 ? ctx->n_cu : 256)) {
+      if (PP_API(pp4_launch_wgrad3r)(ctx->stream, p, x_hi, x_lo, dy_hi, dy_lo, dw, dbias, skip_list, ctx->n_cu > 0 ? ctx->n_cu : 256, variant)) {
         PP_CHECK_LAUNCH(ctx, "pp_conv2d_nhwc_bwd_weight_bf16x3");
         return PP_OK;
       }

@@ -12,6 +12,6 @@ void pp4_launch_igemm4p_fmt1(hipStream_t st, IgemmParams& p, const void* ahi, co
 // the tap-row-reuse weight gradient of 3x3 stride-1 "same" convolutions on plane-stored operands (wgrad3r_kernel): fills the launch
 // fields of p and launches, or returns false when the launch does not meet the kernel's conditions
 bool pp4_launch_wgrad3r_fmt0(hipStream_t st, Wgrad3Params& p, const void* xhi, const void* xlo, const void* dhi, const void* dlo, float* dw,
-                             float* dbias, const int* list, int n_cu);
+                             float* dbias, const int* list, int n_cu, int variant);
 bool pp4_launch_wgrad3r_fmt1(hipStream_t st, Wgrad3Params& p, const void* xhi, const void* xlo, const void* dhi, const void* dlo, float* dw,
-                             float* dbias, const int* list, int n_cu);
+                             float* dbias, const int* list, int n_cu, int variant);

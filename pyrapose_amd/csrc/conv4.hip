@@ -27,6 +27,10 @@
 #define PP_API(name) PP_CAT(name, _fmt0)
 #endif
 #include "conv4.h"
+#ifndef PP_W3W_LA
+#define PP_W3W_LA 2  // wgrad3w: fragment reads in flight ahead of the MFMAs, in units
+#endif
+
 namespace {
 #include "planes_fmt.h"
 #include "conv3_shared.h"
@@ -720,6 +724,411 @@ __global__ __launch_bounds__(256, 1) void wgrad3r_kernel(const Wgrad3Params p, c
   }
 }
 
+
+// ============================================================================================================================
+// wgrad3w_kernel: wgrad3r's tiles with the two halves of a step on DIFFERENT WAVES (round 4, second attempt; dense reduction only).
+// What wgrad3r showed: with ONE wave per SIMD its step is the SUM of a global-load latency (one step of look-ahead), ~200 address
+// instructions and the MFMA block.  Here a workgroup is 8 waves = two per SIMD, 256 registers each:
+//  * waves 0-3 ("consumers") hold the 192 accumulators and do nothing but transposing fragment reads and MFMAs -- 18 units per
+//    step, the reads of unit U + 2 in front of the MFMAs of unit U (alone they run at the MFMA rate: 0.75 us per step);
+//  * waves 4-7 ("producers") have no accumulators.  Waves 4, 5 stage the EVEN steps, waves 6, 7 the ODD ones: a pair stores its
+//    step's tiles in one phase (between two barriers) and issues the loads of its next step -- two phases ahead -- right behind the
+//    stores, so every load has two full steps to land with ONE register set per wave and plain, compiler-counted waits (a first
+//    version kept two sets per wave in flight behind inline-assembly loads: hipcc's own bookkeeping merges the unrolled loop's
+//    halves conservatively, and with hand-counted waits the loop-carried, still-in-flight registers can be COPIED at the back edge
+//    -- a hang that came and went with unrelated changes).  In its other phase a pair walks its positions: +64 per step, a
+//    decode from scratch only when the walk leaves its image.
+//  * one s_barrier per step, two LDS buffers: in phase k (the consumers read buffer (k - 1) & 1) step k is stored into buffer k & 1.
+// Tile decode, reduction space (positions with a pad behind every image row), f32 atomics and bias sums are wgrad3r's.
+// What it reaches (profiles/r04_wgrad_producer_consumer_waves.txt): 5-19 % under wgrad3f per dense P16 launch, +4 % on the
+// dense-backward step -- and NOT the 1.5x the split was built for: the consumers alone run a step in 0.75-0.9 us, the producers
+// alone in 0.57 us, both together in the SUM of the two.  Staging a step's 42 KB costs each SIMD ~1 100 cycles in which its
+// consumer wave issues nothing, whichever wave stages and however (register staging as here; LDS-DMA into a ring of three
+// buffers with a table of row offsets: built, parity-green, the same sum; stores spread over the phase: slower).  On this CU the
+// bytes staged per MFMA set the time, not who stages them.
+__global__ __launch_bounds__(512, 1) void wgrad3w_kernel(const Wgrad3Params p, const void* __restrict__ g_x0, const void* __restrict__ g_x1,
+                                                         unsigned x_bytes, const void* __restrict__ g_d0, const void* __restrict__ g_d1,
+                                                         unsigned d_bytes, float* __restrict__ g_dw, float* __restrict__ g_dbias) {
+  constexpr int TM = 2, TN = 2, BM = 128, BN = 128, BK = 32;
+  constexpr int XR = BK + 2;                 // x rows per buffer: positions m - 1 .. m + 32
+  constexpr int PA = BM + 32, PB = BN + 32;  // LDS pitches in 16-bit elements (row + 64 bytes: conflict-free transposing reads)
+  constexpr int XB = XR * PA, GB = BK * PB;  // elements per plane and buffer
+  constexpr int BUF = 2 * XB + 2 * GB;       // 42 240 bytes
+  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= 4;
+  const int rw = wave & 3;  // index of the wave within its role
+  const float inv_g = p.inv_scale ? *p.inv_scale : 1.f;
+  const int wm = rw >> 1, wn = rw & 1;
+  int b = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int tile_n = b % p.n_tiles_n;
+  b /= p.n_tiles_n;
+  const int tile_k = b % p.n_tiles_k;
+  const int split = b / p.n_tiles_k;
+  const int ty = tile_k / p.k_tiles_per_tap;
+  const int ci0 = (tile_k - ty * p.k_tiles_per_tap) * BM;
+  const int n0 = tile_n * BN;
+  const int m_begin = split * p.rows_per_split;
+  const int m_end = min(p.Mp, m_begin + p.rows_per_split);
+  const int n_steps = (m_end - m_begin + BK - 1) / BK;
+  const bool do_bias = (g_dbias != nullptr) && (tile_k == 0);
+  // producers: 128 threads per pair, 8 per row; thread row `prow` stages positions m + prow and m + prow + 16
+  const int ptid = tid & 127, prow = ptid >> 3, q8 = ptid & 7;
+  float4 bsum[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bsum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto barrier = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  if (producer) {
+    const int pair = rw >> 1;  // 0: even steps, 1: odd steps
+    const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_x0), 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_x1), 0, x_bytes - 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_d0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_d0), 0, d_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_d1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_d1), 0, d_bytes - 16, 0x00020000);
+    uint4 rx[2][2], rxl[2][2], rd[2][2], rdl[2][2], re[2], rel[2];  // [row of the thread][channel group]; re: the thread's extra x row
+    int d_OW, d_OH, d_xx, d_y, d_img;
+    bool d_ok;
+    auto decode = [&](int q) __attribute__((always_inline)) {  // position -> level, image, (y, x); x == W is the pad
+      int qbeg = p.pos_begin[0], rbeg = p.seg[0].row_begin;
+      d_OH = p.seg[0].OH; d_OW = p.seg[0].OW;
+#pragma unroll
+      for (int s = 1; s < PP_MAX_SEG; ++s) {
+        const bool in = s < p.n_seg && q >= p.pos_begin[s];
+        qbeg = in ? p.pos_begin[s] : qbeg;
+        rbeg = in ? p.seg[s].row_begin : rbeg;
+        d_OH = in ? p.seg[s].OH : d_OH;
+        d_OW = in ? p.seg[s].OW : d_OW;
+      }
+      const int qc = q < 0 ? 0 : (q < p.Mp ? q : p.Mp - 1);
+      const int w1 = d_OW + 1, hw1 = d_OH * w1;
+      int rem;
+      const int n = div_small(qc - qbeg, hw1, __frcp_rn((float)hw1), &rem);
+      d_y = div_small(rem, w1, __frcp_rn((float)w1), &d_xx);
+      d_img = rbeg + n * d_OH * d_OW;  // first pixel of the image ("same" geometry: x and dy share the row space)
+      d_ok = q >= 0 && q < p.Mp && d_xx < d_OW;
+    };
+    auto x_off = [&]() __attribute__((always_inline)) -> int {  // byte offset of the decoded position's x pixel at kernel row ty, or out of range
+      const int sy = d_y + ty - 1;
+      const int o = ((d_img + sy * d_OW + d_xx) * p.ld_src + ci0) * 4 + 32 * q8;
+      return o | ((d_ok && (unsigned)sy < (unsigned)d_OH) ? 0 : PP_BUF_OOB);
+    };
+    // the walk: this pair's next step is 2 BK positions on
+    int w_q[2], w_xx[2], w_y[2], w_img[2], w_W[2], w_H[2];
+    bool w_ok[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      w_q[r] = m_begin + (pair - 2) * BK + prow + 16 * r;
+      w_xx[r] = 0; w_y[r] = 0; w_img[r] = 0; w_W[r] = 1 << 29; w_H[r] = 0;
+      w_ok[r] = false;
+    }
+    int o_x[2] = {PP_BUF_OOB, PP_BUF_OOB}, o_d[2][2] = {{PP_BUF_OOB, PP_BUF_OOB}, {PP_BUF_OOB, PP_BUF_OOB}}, o_e = PP_BUF_OOB;
+    const int cofs = ci0 * 4 + 32 * q8;
+    auto prep = [&]() __attribute__((always_inline)) {
+      o_e = PP_BUF_OOB;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        w_q[r] += 2 * BK;
+        w_xx[r] += 2 * BK;
+        while (w_xx[r] > w_W[r]) {  // (row length W + 1: positions 0 .. W, W = the pad)
+          w_xx[r] -= w_W[r] + 1;
+          ++w_y[r];
+        }
+        if (w_y[r] >= w_H[r] || w_q[r] >= p.Mp) {
+          decode(w_q[r]);
+          w_xx[r] = d_xx; w_y[r] = d_y; w_img[r] = d_img; w_W[r] = d_OW; w_H[r] = d_OH;
+          w_ok[r] = d_ok;
+        } else {
+          w_ok[r] = w_xx[r] < w_W[r];
+        }
+        const int sy = w_y[r] + ty - 1;
+        const bool vy = (unsigned)sy < (unsigned)w_H[r];
+        const int lin = w_img[r] + w_y[r] * w_W[r] + w_xx[r];  // (at a pad: the first pixel of the next row -- never read)
+        const int linx = lin + (ty - 1) * w_W[r];
+        o_x[r] = (linx * p.ld_src * 4 + cofs) | ((w_ok[r] && vy) ? 0 : PP_BUF_OOB);
+        const int dyo = (lin * p.ld_dy + n0) * 4 + 32 * q8;
+        const bool in_rng = w_ok[r] && w_q[r] < m_end;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) o_d[r][j] = dyo | ((in_rng && (n0 + 8 * (q8 + 8 * j) < p.ld_dy)) ? 0 : PP_BUF_OOB);
+        // the two extra x rows are neighbours of positions this thread already has: x row 0 (position m - 1) belongs to thread
+        // row 0, x row 33 (position m + 32) to the second row of thread row 15
+        if (r == 0 && prow == 0) {  // position q - 1: the previous pixel of this image row, or the pad before it (zeros)
+          o_e = ((linx - 1) * p.ld_src * 4 + cofs) | ((w_xx[r] > 0 && vy && w_q[r] < p.Mp) ? 0 : PP_BUF_OOB);
+        } else if (r == 1 && prow == 15) {  // position q + 1
+          if (w_q[r] + 1 >= p.Mp) {
+          } else if (w_xx[r] < w_W[r]) {  // the next pixel of this row, or its pad
+            o_e = ((linx + 1) * p.ld_src * 4 + cofs) | ((w_xx[r] + 1 < w_W[r] && vy) ? 0 : PP_BUF_OOB);
+          } else if (w_y[r] + 1 < w_H[r]) {  // q is a pad: the first pixel of the next image row
+            const int sy2 = w_y[r] + ty;
+            o_e = ((w_img[r] + sy2 * w_W[r]) * p.ld_src * 4 + cofs) | (((unsigned)sy2 < (unsigned)w_H[r]) ? 0 : PP_BUF_OOB);
+          } else {  // the first pixel of the next image (or level)
+            decode(w_q[r] + 1);
+            o_e = x_off();
+          }
+        }
+      }
+    };
+    auto issue = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          rx[r][j] = buf_load16(rs_x0, o_x[r], 256 * j);
+          rxl[r][j] = buf_load16(rs_x1, o_x[r], 256 * j);
+          rd[r][j] = buf_load16(rs_d0, o_d[r][j], 256 * j);
+          rdl[r][j] = buf_load16(rs_d1, o_d[r][j], 256 * j);
+        }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        re[j] = buf_load16(rs_x0, o_e, 256 * j);
+        rel[j] = buf_load16(rs_x1, o_e, 256 * j);
+      }
+    };
+    unsigned short* const buf = smem + pair * BUF;  // (an even step's tiles live in buffer 0, an odd step's in buffer 1)
+    unsigned short* const Xhi = buf;
+    unsigned short* const Xlo = buf + XB;
+    unsigned short* const Ghi = buf + 2 * XB;
+    unsigned short* const Glo = Ghi + GB;
+    auto store_step = [&]() __attribute__((always_inline)) {
+      if (do_bias) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const unsigned hw4[4] = {rd[r][j].x, rd[r][j].y, rd[r][j].z, rd[r][j].w}, lw4[4] = {rdl[r][j].x, rdl[r][j].y, rdl[r][j].z, rdl[r][j].w};
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fmt_value2(hw4[e], lw4[e], &v[2 * e], &v[2 * e + 1]);
+            bsum[2 * j].x += v[0]; bsum[2 * j].y += v[1]; bsum[2 * j].z += v[2]; bsum[2 * j].w += v[3];
+            bsum[2 * j + 1].x += v[4]; bsum[2 * j + 1].y += v[5]; bsum[2 * j + 1].z += v[6]; bsum[2 * j + 1].w += v[7];
+          }
+      }
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = 8 * (q8 + 8 * j), row = prow + 16 * r;
+          *reinterpret_cast<uint4*>(Xhi + (row + 1) * PA + col) = rx[r][j];
+          *reinterpret_cast<uint4*>(Xlo + (row + 1) * PA + col) = rxl[r][j];
+          uint4 gl = rdl[r][j];
+#if PP_FMT == 1
+          // dy's lo units with their bytes swapped once, here, instead of in every fragment of every tap (see wgrad_step)
+          gl.x = __builtin_amdgcn_perm(gl.x, gl.x, 0x02030001u); gl.y = __builtin_amdgcn_perm(gl.y, gl.y, 0x02030001u);
+          gl.z = __builtin_amdgcn_perm(gl.z, gl.z, 0x02030001u); gl.w = __builtin_amdgcn_perm(gl.w, gl.w, 0x02030001u);
+#endif
+          *reinterpret_cast<uint4*>(Ghi + row * PB + col) = rd[r][j];
+          *reinterpret_cast<uint4*>(Glo + row * PB + col) = gl;
+        }
+      if (prow == 0 || prow == 15) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = 8 * (q8 + 8 * j);
+          const int er = prow == 0 ? 0 : BK + 1;  // x row 0 = position m - 1, x row 33 = position m + 32
+          *reinterpret_cast<uint4*>(Xhi + er * PA + col) = re[j];
+          *reinterpret_cast<uint4*>(Xlo + er * PA + col) = rel[j];
+        }
+      }
+    };
+    // phase 0 (before the first barrier): both pairs issue their first step; pair 0 also stores step 0 and issues step 2
+    prep();
+    issue();
+    prep();
+    if (pair == 0) {
+      store_step();
+      issue();
+    }
+    barrier();
+    // phase ph (the consumers read buffer (ph - 1) & 1): the pair of step ph stores it into buffer ph & 1 and issues step ph + 2
+    // (offsets ready since its last idle phase); the other pair has the phase for its address walk (the step after the one in flight)
+    for (int ph = 1; ph <= n_steps; ++ph) {
+      if ((ph & 1) == pair) {
+        store_step();
+        issue();
+      } else {
+        prep();
+      }
+      barrier();
+    }
+  } else {
+    floatx16 acc[3][TM][TN];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int c = 0; c < TN; ++c)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][a][c][r] = 0.f;
+    // transposed-read lane roles (16-lane groups): group g -> columns 16 (g & 1) .., pixel half hh = g >> 1 (see wgrad3f_kernel)
+    const int grp = lane >> 4, gi = lane & 15, gq = gi >> 2, gp = gi & 3;
+    const int cbase = 16 * (grp & 1), hh = grp >> 1;
+    const int il = lane & 31, h = lane >> 5;
+    const int xcol0 = wm * 32 * TM + cbase + 4 * gp, gcol0 = wn * 32 * TN + cbase + 4 * gp;
+    auto compute = [&](const unsigned short* buf) __attribute__((always_inline)) {
+      // (one lane pointer per operand and step, everything else a compile-time element offset: the reads take it as their immediate.
+      // With the offsets spelled as one integer expression hipcc kept six address registers -- two more than the kernel has)
+      const unsigned short* const xl = buf + (8 * hh + gq) * PA + xcol0;
+      const unsigned short* const gl_ = buf + (8 * hh + gq) * PB + gcol0;
+      constexpr int Xhi = 0, Xlo = XB, Ghi = 2 * XB, Glo = 2 * XB + GB;  // plane offsets in elements
+      // x row of dy pixel k at tap tx: k + tx (LDS x row 0 = position m - 1)
+      auto xfrag = [&](int plane, int s, int a, int tx) __attribute__((always_inline)) -> uint4 {
+        const int c0 = plane + (16 * s + tx) * PA + a * 32;
+        const bf16x8 t = tr_frag(xl, c0, c0 + 4 * PA);
+        return *reinterpret_cast<const uint4*>(&t);
+      };
+      auto gfrag = [&](int plane, int s, int c) __attribute__((always_inline)) -> uint4 {
+        const int c0 = plane + 16 * s * PB + c * 32;
+        const bf16x8 t = tr_frag(gl_, c0, c0 + 4 * PB);
+        return *reinterpret_cast<const uint4*>(&t);
+      };
+      // Left alone hipcc emits [reads of a unit; lgkmcnt(0); its MFMAs]: an LDS latency per pair of MFMAs.  Here the reads of unit
+      // U + LA are issued in front of the MFMAs of unit U, unit boundaries are scheduling barriers, and the compiler's own (counted)
+      // lgkmcnt waits do the rest.
+      constexpr int LA = PP_W3W_LA;
+#if PP_FMT == 1
+      // 18 units per step: the six (tap, a) pairs of the e5m2 planes (4 transposing reads -> 2 scaled MFMAs), then of the half planes
+      // of s = 0, then of s = 1 (2 reads -> 2 MFMAs) -- dy's fragments of the three phases are then live one phase at a time (16 + 8
+      // registers instead of 32; with 192 accumulators that is the difference between spilling and not)
+      constexpr int NU = 18;
+      intx8 gq8[TN];
+      uint4 gh[2][TN];
+      auto rd_g = [&](int ph) __attribute__((always_inline)) {
+        if (ph == 0) {
+#pragma unroll
+          for (int c = 0; c < TN; ++c) {
+            const uint4 u0 = gfrag(Glo, 0, c), u1 = gfrag(Glo, 1, c);
+            gq8[c][0] = (int)u0.x; gq8[c][1] = (int)u0.y; gq8[c][2] = (int)u0.z; gq8[c][3] = (int)u0.w;
+            gq8[c][4] = (int)u1.x; gq8[c][5] = (int)u1.y; gq8[c][6] = (int)u1.z; gq8[c][7] = (int)u1.w;
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < TN; ++c) gh[ph - 1][c] = gfrag(Ghi, ph - 1, c);
+        }
+      };
+      uint4 F[NU][2];
+      auto rd = [&](int U) __attribute__((always_inline)) {
+        const int ph = U / 6, tx = (U % 6) >> 1, a_ = U & 1;
+        if (ph == 0) {
+          F[U][0] = xfrag(Xlo, 0, a_, tx);
+          F[U][1] = xfrag(Xlo, 1, a_, tx);
+        } else {
+          F[U][0] = xfrag(Xhi, ph - 1, a_, tx);
+        }
+      };
+      auto mm = [&](int U) __attribute__((always_inline)) {
+        const int ph = U / 6, tx = (U % 6) >> 1, a_ = U & 1;
+        if (ph == 0) {
+          intx8 xq8;
+          xq8[0] = (int)F[U][0].x; xq8[1] = (int)F[U][0].y; xq8[2] = (int)F[U][0].z; xq8[3] = (int)F[U][0].w;
+          xq8[4] = (int)F[U][1].x; xq8[5] = (int)F[U][1].y; xq8[6] = (int)F[U][1].z; xq8[7] = (int)F[U][1].w;
+#pragma unroll
+          for (int c = 0; c < TN; ++c)
+            acc[tx][a_][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xq8, gq8[c], acc[tx][a_][c], 1, 1, 0, P16_SCALES, 1, P16_SCALES);
+        } else {
+          const halfx8 xh = *reinterpret_cast<const halfx8*>(&F[U][0]);
+#pragma unroll
+          for (int c = 0; c < TN; ++c)
+            acc[tx][a_][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, *reinterpret_cast<const halfx8*>(&gh[ph - 1][c]), acc[tx][a_][c], 0, 0, 0);
+        }
+      };
+      rd_g(0);
+#pragma unroll
+      for (int U = 0; U < LA; ++U) rd(U);
+#pragma unroll
+      for (int U = 0; U < NU; ++U) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (U + LA == 6) rd_g(1);
+        if (U + LA == 12) rd_g(2);
+        if (U + LA < NU) rd(U + LA);
+        mm(U);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#else
+      // bf16 pairs: 12 units per step -- (s, tap, a): 4 reads -> 6 MFMAs; dy's fragments of half-step s read two units early
+      constexpr int NU = 12;
+      uint4 gh[2][TN], gl[2][TN];
+      auto rd_g = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < TN; ++c) {
+          gh[s][c] = gfrag(Ghi, s, c);
+          gl[s][c] = gfrag(Glo, s, c);
+        }
+      };
+      uint4 F[NU][2];
+      auto rd = [&](int U) __attribute__((always_inline)) {
+        const int s = U / 6, tx = (U % 6) >> 1, a_ = U & 1;
+        F[U][0] = xfrag(Xhi, s, a_, tx);
+        F[U][1] = xfrag(Xlo, s, a_, tx);
+      };
+      auto mm = [&](int U) __attribute__((always_inline)) {
+        const int s = U / 6, tx = (U % 6) >> 1, a_ = U & 1;
+        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(&F[U][0]), xl2 = *reinterpret_cast<const bf16x8*>(&F[U][1]);
+#pragma unroll
+        for (int c = 0; c < TN; ++c) {
+          acc[tx][a_][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl2, *reinterpret_cast<const bf16x8*>(&gh[s][c]), acc[tx][a_][c], 0, 0, 0);
+          acc[tx][a_][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, *reinterpret_cast<const bf16x8*>(&gl[s][c]), acc[tx][a_][c], 0, 0, 0);
+          acc[tx][a_][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, *reinterpret_cast<const bf16x8*>(&gh[s][c]), acc[tx][a_][c], 0, 0, 0);
+        }
+      };
+      rd_g(0);
+#pragma unroll
+      for (int U = 0; U < LA; ++U) rd(U);
+#pragma unroll
+      for (int U = 0; U < NU; ++U) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (U + LA == 6) rd_g(1);
+        if (U + LA < NU) rd(U + LA);
+        mm(U);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    };
+    barrier();
+    for (int step = 0; step < n_steps; ++step) {
+      compute(smem + (step & 1) * BUF);
+      barrier();
+    }
+    // reduction over the row splits: f32 atomics into dW (fire and forget; see wgrad3f_kernel)
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ci = ci0 + wm * 32 * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const long long row = (long long)((ty * 3 + tx) * p.Cin + ci) * p.ld_w;
+#pragma unroll
+          for (int c = 0; c < TN; ++c) {
+            const int co = n0 + wn * 32 * TN + c * 32 + il;
+            if (co < p.Cout) atomicAdd(g_dw + row + co, acc[tx][a][c][r] * inv_g);
+          }
+        }
+  }
+  if (do_bias) {  // (uniform over the workgroup; the producers hold the sums: 256 threads, 16 rows x 8 column groups per pair)
+    float* red = reinterpret_cast<float*>(smem);  // [32][BN] floats
+    __syncthreads();
+    if (producer) {
+      const int rrow = ((tid & 255) >> 7) * 16 + prow;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        *reinterpret_cast<float4*>(red + rrow * BN + 8 * (q8 + 8 * j)) = bsum[2 * j];
+        *reinterpret_cast<float4*>(red + rrow * BN + 8 * (q8 + 8 * j) + 4) = bsum[2 * j + 1];
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) s += red[r * BN + tid];
+      if (n0 + tid < p.Cout) atomicAdd(g_dbias + n0 + tid, s * inv_g);
+    }
+  }
+}
+
 }  // namespace
 
 void PP_API(pp4_launch_igemm4p)(hipStream_t st, IgemmParams& p, const void* ahi, const void* whi, const void* wlo, int w_rows, int w_ld8,
@@ -747,8 +1156,9 @@ void PP_API(pp4_launch_igemm4p)(hipStream_t st, IgemmParams& p, const void* ahi,
 // the tap-row-reuse weight gradient (wgrad3r_kernel); returns false when the launch does not meet its conditions (the caller then
 // takes wgrad3f).  list: the listed 32-row blocks of dy (pp_row_block_list) or NULL.
 bool PP_API(pp4_launch_wgrad3r)(hipStream_t st, Wgrad3Params& p, const void* xhi, const void* xlo, const void* dhi, const void* dlo, float* dw,
-                                float* dbias, const int* list, int n_cu) {
+                                float* dbias, const int* list, int n_cu, int variant) {
   if (!(p.kh == 3 && p.kw == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && p.Cin % 128 == 0 && xhi && dhi)) return false;
+  if (variant == 2 && list) return false;  // wgrad3w: dense reductions only
   int min_ow = 1 << 30;
   long long pos = 0;
   for (int i = 0; i < p.n_seg; ++i) {
@@ -796,6 +1206,11 @@ bool PP_API(pp4_launch_wgrad3r)(hipStream_t st, Wgrad3Params& p, const void* xhi
   p.rows_per_split = rps;
   if (p.sp_min_steps < 1) p.sp_min_steps = 1;
   if (getenv("PP_CONV_DEBUG")) fprintf(stderr, "wgrad3r tiles %d (3 taps each) splits %d (M %d)%s\n", tiles, splits, p.M, list ? " listed blocks" : "");
+  if (variant == 2) {  // wgrad3w: producer / consumer waves (dense reductions; listed blocks stay with wgrad3f)
+    hipLaunchKernelGGL(wgrad3w_kernel, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, p, xhi, xlo, (unsigned)x_bytes, dhi, dlo,
+                       (unsigned)d_bytes, dw, dbias);
+    return true;
+  }
   if (list)
     hipLaunchKernelGGL((wgrad3r_kernel<true>), dim3((unsigned)(tiles * splits)), dim3(256), 0, st, p, xhi, xlo, (unsigned)x_bytes, dhi, dlo,
                        (unsigned)d_bytes, dw, dbias, list);

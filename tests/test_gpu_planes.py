@@ -683,7 +683,7 @@ def test_tap_row_reuse_weight_gradient_matches_wgrad3f(ctx, monkeypatch, case):
     skip = ops.row_block_list(ctx, dys, cout)
     ld_w = (cout + 15) // 16 * 16
     out = {}
-    for r in ("0", "1"):
+    for r in ("0", "1", "2"):  # wgrad3f / wgrad3r / wgrad3w (producer + consumer waves)
         monkeypatch.setenv("PP_WGRAD3R", r)
         dw, db = torch.zeros((k * k * cin, ld_w), device="cuda"), torch.zeros((ld_w,), device="cuda")
         ops.conv_bwd_weight3(ctx, d, None, None, dw, db, x_planes=xp, dy_planes=gp)
@@ -693,11 +693,12 @@ def test_tap_row_reuse_weight_gradient_matches_wgrad3f(ctx, monkeypatch, case):
         out[r] = (dw, db, dws, dbs)
     monkeypatch.delenv("PP_WGRAD3R", raising=False)
     tol = 3e-5 if FMT[0] == 1 else 1e-5  # (two evaluations of one arithmetic: f32 summation order)
-    for i in range(4):
-        a, b_ = out["0"][i], out["1"][i]
-        assert float(b_.abs().max()) > 0
-        assert float((a - b_).abs().max()) <= tol * float(a.abs().max()), (i, float((a - b_).abs().max()), float(a.abs().max()))
-    assert float(out["1"][0][:, cout:].abs().max()) == 0 if ld_w > cout else True
+    for r in ("1", "2"):
+        for i in range(4):
+            a, b_ = out["0"][i], out[r][i]
+            assert float(b_.abs().max()) > 0
+            assert float((a - b_).abs().max()) <= tol * float(a.abs().max()), (r, i, float((a - b_).abs().max()), float(a.abs().max()))
+        assert float(out[r][0][:, cout:].abs().max()) == 0 if ld_w > cout else True
     # float64: dW[ty][tx] = sum over pixels of x[pixel + offset]^T dy[pixel], image by image and level by level
     xv, gv = merged(xp).double(), merged(gp).double()[:, :cout]
     ref = torch.zeros((k, k, cin, cout), dtype=torch.float64, device="cuda")
