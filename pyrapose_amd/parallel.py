@@ -220,8 +220,17 @@ class DataParallel(object):
         self.native = None
         on_gpu = engine.params.grad.is_cuda
         env = os.environ.get("PP_DP_NATIVE")
+        explicit = native is True
         if native is None:
-            native = (env != "0") and on_gpu and NativeComm.available() and ((self.active and dist.get_backend(group) == "nccl") or env == "1")
+            native = (env != "0") and on_gpu and ((self.active and dist.get_backend(group) == "nccl") or env == "1")
+            want = bool(native)
+            native = want and NativeComm.available()
+            if want and self.active and self.world > 1:
+                # every rank takes the SAME path: a rank whose library cannot load RCCL would otherwise sit in torch.distributed's
+                # all-reduce while the others wait in ncclCommInitRank
+                flag = torch.tensor([1 if native else 0], dtype=torch.int32, device=engine.params.grad.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                native = bool(int(flag.item()))
         if native:
             if not (on_gpu and NativeComm.available()):
                 raise RuntimeError("DataParallel(native=True): needs device tensors and a loadable librccl.so (PP_RCCL_LIB)")
@@ -230,7 +239,23 @@ class DataParallel(object):
             box = [NativeComm.unique_id(dev) if rank == 0 else None]
             if self.active and self.world > 1:
                 dist.broadcast_object_list(box, src=0, group=group)  # (the id's only journey; the data path never sees torch.distributed)
-            self.native = NativeComm(dev, self.world, rank, box[0])
+            try:
+                self.native = NativeComm(dev, self.world, rank, box[0])
+                err = None
+            except Exception as e:  # noqa: BLE001 -- (ncclCommInitRank reports a failure on every rank of the communicator)
+                self.native, err = None, e
+            if self.active and self.world > 1:
+                flag = torch.tensor([0 if err else 1], dtype=torch.int32, device=engine.params.grad.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                if not int(flag.item()) and self.native is not None:
+                    self.native.close()
+                    self.native = None
+            if self.native is None:
+                if explicit or not self.active:
+                    raise RuntimeError("DataParallel: the library-owned RCCL communicator could not be created (%s)" % (err,))
+                import warnings
+                warnings.warn("pyrapose_amd.parallel: library-owned RCCL communicator unavailable (%s): gradient all-reduce through "
+                              "torch.distributed" % (err,))
         self.buckets = plan_buckets(engine.params.entries, engine.bwd_ops, bucket_bytes)
         if os.environ.get("PP_DP_DEBUG") == "1":
             rank = dist.get_rank(group) if self.active else 0
