@@ -18,6 +18,7 @@ SHAPES = {
     "regout": (8, [(60, 80), (30, 40), (15, 20)], 512, 144, 3, 1, 1),
     "cls": (8, [(60, 80), (30, 40), (15, 20)], 256, 256, 3, 1, 1),
     "mask": (8, [(60, 80)], 256, 256, 3, 1, 1),
+    "cls14": (14, [(60, 80), (30, 40), (15, 20)], 256, 256, 3, 1, 1),  # rows of the class head + the mask head in ONE launch (88 200): 2.7 rounds of 256 x 128 tiles
     "res5": (8, [(15, 20)], 512, 512, 3, 1, 1),
     "res5c": (8, [(15, 20)], 512, 2048, 1, 1, 0),
     "res5a": (8, [(15, 20)], 2048, 512, 1, 1, 0),
