@@ -9,7 +9,7 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(igemm4x_kernel|igemm3[fx]?_kernel|igemm2[fx]?_kernel|wgrad2f?_kernel|wgrad3f?_kernel|igemm_kernel|wgrad_kernel|splitk_finish_kernel)(<[^>]*>)?", name)
+    m = re.search(r"(igemm4[xp]_kernel|igemm3[fx]?_kernel|igemm2[fx]?_kernel|wgrad2f?_kernel|wgrad3[frw]?_kernel|igemm_kernel|wgrad_kernel|splitk_finish_kernel)(<[^>]*>)?", name)
     return (m.group(1) + (m.group(2) or "")) if m else None
 
 
