@@ -204,6 +204,9 @@ class NativeComm(object):
         self.ctx.close()
 
 
+_NATIVE_COMMS = {}  # (device, id(group), world) -> NativeComm shared by the DataParallel objects of this process
+
+
 class DataParallel(object):
     def __init__(self, engine, group=None, bucket_bytes=None, native=None):
         """native: True = the gradient / count all-reduces run on the library's own RCCL communicator (NativeComm: pp_allreduce_bucket
@@ -231,10 +234,16 @@ class DataParallel(object):
                 flag = torch.tensor([1 if native else 0], dtype=torch.int32, device=engine.params.grad.device)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
                 native = bool(int(flag.item()))
+        dev = (engine.params.grad.device.index or 0) if on_gpu else -1
+        cache_key = (dev, id(group) if group is not None else 0, self.world)
+        if native and cache_key in _NATIVE_COMMS:
+            # one communicator per (device, group) and process: a second engine on the same ranks (bench.py builds one per measured
+            # mode, one after the other) reuses it instead of paying ncclCommInitRank again -- every rank takes this branch together
+            self.native = _NATIVE_COMMS[cache_key]
+            native = False
         if native:
             if not (on_gpu and NativeComm.available()):
                 raise RuntimeError("DataParallel(native=True): needs device tensors and a loadable librccl.so (PP_RCCL_LIB)")
-            dev = engine.params.grad.device.index or 0
             rank = dist.get_rank(group) if self.active else 0
             box = [NativeComm.unique_id(dev) if rank == 0 else None]
             if self.active and self.world > 1:
@@ -250,6 +259,8 @@ class DataParallel(object):
                 if not int(flag.item()) and self.native is not None:
                     self.native.close()
                     self.native = None
+            if self.native is not None and self.active:
+                _NATIVE_COMMS[cache_key] = self.native
             if self.native is None:
                 if explicit or not self.active:
                     raise RuntimeError("DataParallel: the library-owned RCCL communicator could not be created (%s)" % (err,))
