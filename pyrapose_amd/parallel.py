@@ -259,8 +259,8 @@ class DataParallel(object):
                 if not int(flag.item()) and self.native is not None:
                     self.native.close()
                     self.native = None
-            if self.native is not None and self.active:
-                _NATIVE_COMMS[cache_key] = self.native
+            if self.active:
+                _NATIVE_COMMS[cache_key] = self.native  # (None after a failure: the next engine does not try again)
             if self.native is None:
                 if explicit or not self.active:
                     raise RuntimeError("DataParallel: the library-owned RCCL communicator could not be created (%s)" % (err,))

@@ -246,3 +246,119 @@ def test_bucket_plan_and_batch_dealing_at_world_4_and_8(world):
         seen += [(i * world + rank) % n_batches for i in range(steps)]
     assert set(seen) == set(range(n_batches))                      # every batch of the epoch is visited
     assert len(seen) - n_batches < world                           # at most one partial global step wraps around
+
+
+def _path_worker(rank, world, port, case, q):
+    """DataParallel's choice between the library-owned RCCL communicator and torch.distributed, with a stand-in for NativeComm
+    (no GPU here): the ranks must end up on the SAME path whatever one of them finds."""
+    import warnings
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["PP_DP_NATIVE"] = "1"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pyrapose_amd import parallel
+
+    class FakeComm(object):
+        made, closed = 0, 0
+
+        def __init__(self, dev, world_, rank_, uid):
+            assert uid == b"u" * 128 and world_ == world and rank_ == rank
+            if case == "init_fails_on_rank_1" and rank_ == 1:
+                raise RuntimeError("ncclCommInitRank: unhandled system error")
+            FakeComm.made += 1
+            self.world, self.rank, self.stream = world_, rank_, None
+
+        @staticmethod
+        def available():
+            return not (case == "unavailable_on_rank_1" and rank == 1)
+
+        @staticmethod
+        def unique_id(dev=0):
+            return b"u" * 128
+
+        def allreduce(self, t, after=None):
+            dist.all_reduce(t)
+
+        def allreduce_counts(self, c):
+            dist.all_reduce(c)
+
+        def close(self):
+            FakeComm.closed += 1
+
+    parallel.NativeComm = FakeComm
+    parallel._NATIVE_COMMS.clear()
+
+    class Grad(object):  # a "device" gradient buffer that lives on the CPU
+        is_cuda = True
+        device = torch.device("cpu")
+
+        def __init__(self, n):
+            self.t = torch.zeros(n, dtype=torch.float32)
+
+        def __getitem__(self, s):
+            return self.t[s]
+
+    class Stream(object):
+        def wait_stream(self, other):
+            pass
+
+    entries, total = make_layout([100, 2000, 3000], frozen={0})
+
+    def engine():
+        class Obj(object):
+            pass
+        eng = Obj()
+        eng.params = Obj()
+        eng.params.entries, eng.params.grad = entries, Grad(total)
+        eng.bwd_ops = [FakeOp((e["offset"], e["offset"] + e["count"])) for e in list(entries.values())[:0:-1]]
+        eng.streams = [Stream()]
+        return eng
+
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        dps = [parallel.DataParallel(engine(), bucket_bytes=4096), parallel.DataParallel(engine(), bucket_bytes=4096)]
+    for dp in dps:  # whichever path: the sum over the ranks
+        if dp.native is None:
+            dp.on_gpu = False  # (the stand-in buffer really lives on the CPU: torch.distributed's path must not look for a HIP stream)
+        dp.flat.t[:] = float(rank + 1)
+        c = torch.tensor([rank + 1, 0, 0, 0], dtype=torch.int32)
+        dp.reduce_counts(c)
+        for i in range(len(dp.eng.bwd_ops)):
+            dp.after_bwd_op(i)
+        dp.finish()
+        assert int(c[0]) == 3
+        for n, e in list(entries.items())[1:]:
+            assert bool((dp.flat.t[e["offset"]: e["offset"] + e["count"]] == 3.0).all()), n
+    q.put((rank, [type(dp.native).__name__ for dp in dps], dps[0].native is dps[1].native, FakeComm.made, FakeComm.closed,
+           [str(w.message)[:60] for w in wlist]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["available", "unavailable_on_rank_1", "init_fails_on_rank_1"])
+def test_ranks_agree_on_the_allreduce_path(case):
+    """Every rank takes the library-owned communicator, or every rank takes torch.distributed: a rank that cannot load RCCL, or whose
+    ncclCommInitRank fails, pulls the others onto the fallback with it (no rank is left inside a collective of the other path); the
+    communicator is created once per process and shared by the engines built after the first."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_path_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r = q.get(timeout=120)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(2):
+        kinds, same, made, closed, warns = res[rank]
+        if case == "available":
+            assert kinds == ["FakeComm", "FakeComm"] and same and made == 1 and closed == 0 and not warns
+        elif case == "unavailable_on_rank_1":
+            assert kinds == ["NoneType", "NoneType"] and made == 0 and not warns
+        else:
+            assert kinds == ["NoneType", "NoneType"] and made == (1 if rank == 0 else 0) and closed == made  # (one attempt, not one per engine)
+            assert len(warns) == 1 and "RCCL communicator" in warns[0]
