@@ -609,7 +609,8 @@ def main_worker(args):
                      "f16c8": "conv implicit-GEMM family (igemm3x / igemm3f fwd + bwd-data, wgrad3f) on P16 planes: per 32-deep step 2 x "
                               "v_mfma_f32_32x32x16_f16 + 1 x v_mfma_scale_f32_32x32x64_f8f6f4 (e5m2 cross terms) = 2 MFMA units per product"}.get(
                 mode, "conv implicit-GEMM family (igemm4x = the multi-stage LDS-DMA form of the 512-wide head launches, igemm3x / igemm3f fwd + "
-                      "bwd-data, wgrad3f), one source compiled per plane format: backbone = 3 x v_mfma_f32_32x32x16_bf16 per product "
+                      "bwd-data, wgrad3f; wgrad3w = the producer / consumer-wave form of the dense 512-channel weight gradients), one "
+                      "source compiled per plane format: backbone = 3 x v_mfma_f32_32x32x16_bf16 per product "
                       "(bf16x3); FPN + heads = v_mfma_f32_32x32x16_f16 + half a v_mfma_scale_f32_32x32x64_f8f6f4 per 16-deep step "
                       "(f16c8: 2 MFMA units per product)")
         else:
